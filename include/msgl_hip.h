@@ -1,0 +1,218 @@
+/*
+ * msgl_hip.h -- C-ABI of the MI355X (gfx950) paged-attention serving core.
+ *
+ * This header is the drop-in boundary.  Every entry point replaces one native
+ * interface the reference (sgl-project/mini-sglang) reaches through tvm-ffi or
+ * through its third-party CUDA dependencies (flashinfer / sgl_kernel).  The
+ * reference file:line each function stands in for is cited next to it; paths
+ * are relative to the reference root, `P/` = python/minisgl/, `C/` =
+ * python/minisgl/kernel/csrc/.
+ *
+ * Conventions (mirrors the reference FFI contract):
+ *   - plain pointers + sizes + explicit strides, no torch / DLPack types;
+ *   - all device pointers are raw HIP device addresses; `stream` is a
+ *     hipStream_t passed as void* (the caller's current stream, cf.
+ *     C/include/minisgl/utils.cuh:103-106);
+ *   - every function returns 0 on success, a negative MSGL_E* code otherwise,
+ *     and records a message retrievable with msgl_last_error() (the reference
+ *     throws host::PanicError, C/include/minisgl/utils.h:40-87);
+ *   - callee never allocates, frees or synchronises: every call is legal
+ *     inside hipGraph stream capture;
+ *   - strides are in ELEMENTS of the tensor dtype unless the name says bytes.
+ *
+ * Two shared objects implement it:
+ *   libmsgl_hip.so   everything except the communicator (no RCCL dependency)
+ *   libmsgl_comm.so  msgl_comm_* (links librccl)
+ */
+#ifndef MSGL_HIP_H_
+#define MSGL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSGL_OK 0
+#define MSGL_EINVAL (-1)   /* argument check failed (shape/stride/alignment/dtype) */
+#define MSGL_ELAUNCH (-2)  /* HIP reported a launch error                          */
+#define MSGL_ECOMM (-3)    /* RCCL reported an error                               */
+
+/* dtype codes for 16-bit floating tensors */
+#define MSGL_BF16 0
+#define MSGL_FP16 1
+/* dtype codes for logits */
+#define MSGL_F32 2
+
+#define MSGL_ABI_VERSION 1
+
+/* Last error message of the calling thread ("" if none). */
+const char* msgl_last_error(void);
+int msgl_abi_version(void);
+/* Number of compute units of the current device (0 if no device). */
+int msgl_device_cu_count(void);
+
+/* ------------------------------------------------------------------------
+ * KV pool scatter-store.   Replaces: store_cache (P/kernel/store.py:30-42),
+ * StoreKernel::run / store_kv_cache (C/jit/store.cu:27-121).
+ *   k_cache[indices[w]] = k[w];  v_cache[indices[w]] = v[w]   (byte copy)
+ * row_bytes must be a multiple of 16; all bases/strides 16-byte aligned.
+ * indices are token slots (int32 or int64).
+ * ---------------------------------------------------------------------- */
+int msgl_store_kv(void* k_cache, void* v_cache, const void* indices, int indices_is_i64,
+                  const void* k, const void* v, int64_t num_tokens, int64_t row_bytes,
+                  int64_t cache_stride_bytes, int64_t k_stride_bytes, int64_t v_stride_bytes,
+                  void* stream);
+
+/* ------------------------------------------------------------------------
+ * Embedding gather.  Replaces: indexing (P/kernel/index.py:30-50),
+ * index_kernel / masked_index_kernel (C/jit/index.cu:33-96).
+ *   out[i] = W[idx[i]]                       (has_mask == 0)
+ *   p = idx[i] - start; out[i] = p < length (unsigned) ? W[p] : 0
+ * ---------------------------------------------------------------------- */
+int msgl_embedding_gather(void* out, const void* weight, const void* indices, int indices_is_i64,
+                          int64_t num_indices, int64_t row_bytes, int has_mask, int64_t mask_start,
+                          int64_t mask_length, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Radix-tree key compare (host).  Replaces: fast_compare_key
+ * (C/src/radix.cpp:19-40, P/kernel/radix.py:14-20).  Returns the index of
+ * the first mismatch of two int32/int64 host arrays (>= 0), or MSGL_EINVAL.
+ * ---------------------------------------------------------------------- */
+int64_t msgl_fast_compare_key(const void* a, int64_t len_a, const void* b, int64_t len_b,
+                              int elem_bytes);
+
+/* ------------------------------------------------------------------------
+ * RMSNorm family.  Replaces: flashinfer.rmsnorm / fused_add_rmsnorm as called
+ * at P/layers/norm.py:17,20,36-37 (and the strided 3-D in-place calls of
+ * P/layers/attention.py:50-53).
+ * The logical input is [n0, n1, dim] with element strides (stride0, stride1, 1);
+ * a 2-D [T, H] call passes n1 = 1.  out may alias x.  fp32 math.
+ * ---------------------------------------------------------------------- */
+int msgl_rmsnorm(void* out, const void* x, const void* weight, float eps, int64_t n0, int64_t n1,
+                 int64_t dim, int64_t x_stride0, int64_t x_stride1, int64_t out_stride0,
+                 int64_t out_stride1, int dtype, void* stream);
+/* residual <- x + residual (rounded to dtype);  x <- rmsnorm(fp32 sum) * w */
+int msgl_fused_add_rmsnorm(void* x, void* residual, const void* weight, float eps, int64_t rows,
+                           int64_t dim, int64_t x_stride, int64_t res_stride, int dtype,
+                           void* stream);
+
+/* ------------------------------------------------------------------------
+ * NeoX RoPE in place.  Replaces: flashinfer.apply_rope_with_cos_sin_cache_inplace
+ * at P/layers/rotary.py:45-51.  cos_sin_cache is fp32 [max_pos, head_dim]
+ * = cat(cos, sin) (P/layers/rotary.py:24-32).  q: [T, Hq*D], k: [T, Hk*D]
+ * with row strides (elements).
+ * ---------------------------------------------------------------------- */
+int msgl_rope_neox_inplace(void* q, void* k, const void* positions, int positions_is_i64,
+                           const float* cos_sin_cache, int64_t num_tokens, int num_q_heads,
+                           int num_k_heads, int head_dim, int64_t q_stride, int64_t k_stride,
+                           int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused per-token pass over the qkv row:
+ *   [q-norm, k-norm (optional)] -> NeoX RoPE (in place on q,k) -> scatter k,v
+ * rows to the KV pool at out_loc.  Equivalent to the op sequence of
+ * P/layers/attention.py:47-56 + P/kvcache/mha_pool.py:45-56.
+ * q_norm_w / k_norm_w may be NULL (no qk-norm, e.g. Llama).
+ * ---------------------------------------------------------------------- */
+int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const void* q_norm_w,
+                            const void* k_norm_w, float eps, const void* positions,
+                            int positions_is_i64, const float* cos_sin_cache, void* k_cache,
+                            void* v_cache, const void* out_loc, int out_loc_is_i64,
+                            int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
+                            int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                            int64_t cache_stride, int dtype, void* stream);
+
+/* out[t, j] = silu(x[t, j]) * x[t, d + j].  Replaces flashinfer.silu_and_mul
+ * (P/layers/activation.py:9-12). */
+int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                      int64_t out_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Paged decode attention (one query token per request).  Replaces the decode
+ * phase of flash_attn_with_kvcache (P/attention/fa.py:158-182) and of
+ * BatchDecodeWithPagedKVCacheWrapper.run (P/attention/fi.py:188).
+ *
+ * The page table is the reference's GLOBAL table (P/engine/engine.py:66-73):
+ * int32 [rows, pt_stride], entry (row, t) = token slot of position t.  It is
+ * read in place -- no per-step page-table copy (cf. P/attention/fa.py:92-97).
+ * req_rows[b] gives the table row of request b (NULL: row b).
+ *
+ * Work is split over uniform KV chunks by a device-side plan:
+ *   msgl_attn_decode_plan      once per step (seq_lens -> work list)
+ *   msgl_attn_decode           once per layer (partial attention + merge)
+ * Both are capture-safe; grids are fixed by (max_bs, capacity).
+ * ---------------------------------------------------------------------- */
+/* number of int32 words the plan buffer needs */
+int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);
+/* bytes of fp32 workspace for split-KV partials */
+int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim);
+int msgl_attn_decode_plan(int32_t* plan, const int32_t* seq_lens, int batch, int max_bs,
+                          int capacity, int num_kv_heads, int min_chunk, void* stream);
+int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                     const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
+                     const int32_t* seq_lens, const int32_t* plan, void* workspace, int batch,
+                     int max_bs, int capacity, int num_q_heads, int num_kv_heads, int head_dim,
+                     int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
+                     int64_t out_stride_tok, float sm_scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Paged varlen causal prefill attention (MFMA).  Replaces the prefill phase
+ * of flash_attn_with_kvcache (P/attention/fa.py:158-182) and
+ * BatchPrefillWithPagedKVCacheWrapper.run (P/attention/fi.py:188).
+ * q: [T, Hq, D] (tokens of all requests concatenated, cu_seqlens_q [B+1]);
+ * request b attends keys 0..seq_lens[b]-1 through the page table; query j of
+ * q_len sees keys t <= seq_lens[b] - q_len + j (bottom-right causal mask).
+ * tile_cu [B+1]: exclusive prefix of ceil(q_len_b / MSGL_PREFILL_QTILE).
+ * ---------------------------------------------------------------------- */
+#define MSGL_PREFILL_QTILE 128
+int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
+                      const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
+                      const int32_t* seq_lens, const int32_t* cu_seqlens_q,
+                      const int32_t* tile_cu, int batch, int total_tiles, int num_q_heads,
+                      int num_kv_heads, int head_dim, int64_t q_stride_tok,
+                      int64_t kv_stride_tok, int64_t kv_stride_head, int64_t out_stride_tok,
+                      float sm_scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Sampling.  Replaces torch.argmax at P/engine/sample.py:73-74 and
+ * flashinfer.sampling.{softmax, sampling_from_probs, top_k_sampling_from_probs,
+ * top_p_sampling_from_probs, top_k_top_p_sampling_from_probs}
+ * (P/engine/sample.py:30-45).
+ * logits_dtype: MSGL_BF16 / MSGL_FP16 / MSGL_F32.  out: int32 [rows].
+ * ---------------------------------------------------------------------- */
+int msgl_argmax_rows(int32_t* out, const void* logits, int64_t rows, int64_t vocab,
+                     int64_t row_stride, int logits_dtype, void* stream);
+/* probs[r, :] = softmax(logits[r, :] / temperature[r])   (fp32 out) */
+int msgl_softmax_temperature(float* probs, const void* logits, const float* temperatures,
+                             int64_t rows, int64_t vocab, int64_t logits_stride,
+                             int64_t probs_stride, int logits_dtype, void* stream);
+/* Sample one token per row from probs restricted to top-k then top-p
+ * (top_k == NULL: no top-k, top_p == NULL: no top-p).  Philox(seed, offset+row). */
+int msgl_sample_top_k_top_p(int32_t* out, const float* probs, const int32_t* top_k,
+                            const float* top_p, int64_t rows, int64_t vocab,
+                            int64_t probs_stride, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Tensor-parallel communicator over RCCL (libmsgl_comm.so).  Replaces
+ * NCCLWrapper (C/src/pynccl.cu:72-175) / init_pynccl (P/kernel/pynccl.py:47-78).
+ * ---------------------------------------------------------------------- */
+#define MSGL_UNIQUE_ID_BYTES 128
+typedef struct msgl_comm* msgl_comm_t;
+int msgl_comm_unique_id(char out_id[MSGL_UNIQUE_ID_BYTES]);
+int msgl_comm_create(msgl_comm_t* out, int rank, int world_size,
+                     const char id[MSGL_UNIQUE_ID_BYTES], size_t max_bytes);
+/* in-place SUM all-reduce of `count` 16-bit floats */
+int msgl_comm_all_reduce_sum(msgl_comm_t comm, void* data, size_t count, int dtype, void* stream);
+/* dst[rank*count .. ] <- src of every rank */
+int msgl_comm_all_gather(msgl_comm_t comm, void* dst, const void* src, size_t count, int dtype,
+                         void* stream);
+void* msgl_comm_get_buffer(msgl_comm_t comm);
+int msgl_comm_destroy(msgl_comm_t comm);
+const char* msgl_comm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGL_HIP_H_ */

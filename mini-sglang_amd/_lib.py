@@ -1,0 +1,129 @@
+"""ctypes binding of the C-ABI declared in include/msgl_hip.h.
+
+The shared objects are built in-tree by build.py (hipcc --offload-arch=gfx950).  There is
+no CPU fallback: if a library is missing, `lib()` raises; every wrapper in ops.py goes
+through it, so the product path fails loudly instead of silently computing elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_DIR = _PKG / "lib"
+HIP_SO = LIB_DIR / "libmsgl_hip.so"
+COMM_SO = LIB_DIR / "libmsgl_comm.so"
+
+BF16, FP16, F32 = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+PREFILL_QTILE = 128
+ABI_VERSION = 1
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_u64, _sz = C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/msgl_hip.h one to one
+HIP_SIGNATURES = {
+    "msgl_last_error": (C.c_char_p, []),
+    "msgl_abi_version": (_i, []),
+    "msgl_device_cu_count": (_i, []),
+    "msgl_store_kv": (_i, [_p, _p, _p, _i, _p, _p, _l, _l, _l, _l, _l, _p]),
+    "msgl_embedding_gather": (_i, [_p, _p, _p, _i, _l, _l, _i, _l, _l, _p]),
+    "msgl_fast_compare_key": (_l, [_p, _l, _p, _l, _i]),
+    "msgl_rmsnorm": (_i, [_p, _p, _p, _f, _l, _l, _l, _l, _l, _l, _l, _i, _p]),
+    "msgl_fused_add_rmsnorm": (_i, [_p, _p, _p, _f, _l, _l, _l, _l, _i, _p]),
+    "msgl_rope_neox_inplace": (_i, [_p, _p, _p, _i, _p, _l, _i, _i, _i, _l, _l, _i, _p]),
+    "msgl_qk_norm_rope_store": (
+        _i,
+        [_p, _p, _p, _p, _p, _f, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _l, _l, _l, _l, _i, _p],
+    ),
+    "msgl_silu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
+    "msgl_attn_decode_plan_words": (_l, [_i, _i]),
+    "msgl_attn_decode_workspace_bytes": (_l, [_i, _i, _i]),
+    "msgl_attn_decode_plan": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "msgl_attn_decode": (
+        _i,
+        [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p],
+    ),
+    "msgl_attn_prefill": (
+        _i,
+        [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p],
+    ),
+    "msgl_argmax_rows": (_i, [_p, _p, _l, _l, _l, _i, _p]),
+    "msgl_softmax_temperature": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p]),
+    "msgl_sample_top_k_top_p": (_i, [_p, _p, _p, _p, _l, _l, _l, _u64, _u64, _p]),
+}
+
+COMM_SIGNATURES = {
+    "msgl_comm_unique_id": (_i, [C.c_char_p]),
+    "msgl_comm_create": (_i, [C.POINTER(_p), _i, _i, C.c_char_p, _sz]),
+    "msgl_comm_all_reduce_sum": (_i, [_p, _p, _sz, _i, _p]),
+    "msgl_comm_all_gather": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "msgl_comm_get_buffer": (_p, [_p]),
+    "msgl_comm_destroy": (_i, [_p]),
+    "msgl_comm_last_error": (C.c_char_p, []),
+}
+
+
+class MsglError(RuntimeError):
+    """Raised when a C-ABI call returns a negative code (reference: host::PanicError)."""
+
+
+def _bind(path: Path, signatures: dict) -> C.CDLL:
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} is missing: build it with `python mini-sglang_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path."
+        )
+    dll = C.CDLL(str(path))
+    for name, (res, args) in signatures.items():
+        fn = getattr(dll, name, None)
+        if fn is None:  # declared in the header but not exported: calling it raises
+            MISSING_SYMBOLS.append(name)
+            setattr(dll, name, _missing(name, path))
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    return dll
+
+
+MISSING_SYMBOLS: list[str] = []
+
+
+def _missing(name: str, path: Path):
+    def raiser(*_a, **_k):
+        raise RuntimeError(f"{path.name} does not export {name}; rebuild the library")
+
+    return raiser
+
+
+_hip: C.CDLL | None = None
+_comm: C.CDLL | None = None
+
+
+def lib() -> C.CDLL:
+    global _hip
+    if _hip is None:
+        _hip = _bind(HIP_SO, HIP_SIGNATURES)
+        if _hip.msgl_abi_version() != ABI_VERSION:
+            raise RuntimeError("libmsgl_hip.so ABI version mismatch; rebuild")
+    return _hip
+
+
+def comm_lib() -> C.CDLL:
+    global _comm
+    if _comm is None:
+        _comm = _bind(COMM_SO, COMM_SIGNATURES)
+    return _comm
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc < 0:
+        msg = lib().msgl_last_error().decode(errors="replace")
+        raise MsglError(f"{what or 'msgl call'} failed ({rc}): {msg}")
+
+
+def check_comm(rc: int, what: str = "") -> None:
+    if rc < 0:
+        msg = comm_lib().msgl_comm_last_error().decode(errors="replace")
+        raise MsglError(f"{what or 'msgl comm call'} failed ({rc}): {msg}")

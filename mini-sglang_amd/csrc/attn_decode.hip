@@ -1,0 +1,510 @@
+// Paged decode attention for gfx950: one query token per request, KV read through the
+// reference's token-granular page table.
+//
+// HBM-bound (intensity = GQA group size, 2..8 flop/B), so the design is a streaming one:
+//   * work unit = (request, uniform KV chunk, kv head), produced by a tiny device-side plan
+//     kernel once per step; the attention grid is fixed (persistent waves stride over the
+//     work list) => legal inside hipGraph replay, balanced for ragged sequence lengths;
+//   * one wave per unit, all G query heads of the GQA group packed in that wave so each
+//     K/V byte is fetched from HBM exactly once;
+//   * a 256-B K (or V) row of one token = one 16-lane DPP row, 16 B per lane => every
+//     global_load_dwordx4 wave-instruction reads 4 whole token rows (full 128-B lines);
+//   * q.k via v_dot2c_f32_bf16 on the packed data (no unpack), 16-lane all-reduce with four
+//     DPP adds (no LDS), softmax state (m, l, o) kept per 16-lane row over its token subset
+//     and merged across the 4 rows once per unit;
+//   * K/V tiles double-buffered in registers one 16-token tile ahead (8 KB in flight per
+//     wave), page-table slots prefetched two tiles ahead: no LDS, no barriers.
+// Split-KV partials (fp32 o, m, l) go to a workspace and are merged by a second small
+// kernel; single-chunk requests write their final output directly.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace msgl {
+
+constexpr int kPlanHdr = 4;  // [0] n_items [1] chunk [2] batch [3] reserved
+constexpr float kNegBig = -3.0e38f;
+
+// ------------------------------------------------------------------------------
+// plan: seq_lens -> uniform chunks.  One block, 256 threads.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int block_sum_256(int x, int* red) {
+  const int tid = threadIdx.x;
+  red[tid] = x;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const int r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan,
+                                                          const int* __restrict__ seq_lens, int batch,
+                                                          int max_bs, int capacity, int target_items,
+                                                          int min_chunk) {
+  __shared__ int red[256];
+  const int tid = threadIdx.x;
+  int* item_start = plan + kPlanHdr;
+  int* n_chunks = item_start + max_bs;
+  int* items = n_chunks + max_bs;
+
+  long long local_tok = 0;
+  for (int b = tid; b < batch; b += 256) local_tok += max(seq_lens[b], 0);
+  // totals fit int32: batch * max_seq_len < 2^31 for every supported configuration
+  const int total = block_sum_256((int)local_tok, red);
+
+  int chunk = min_chunk;
+  while (chunk < (1 << 24) && total / chunk > target_items) chunk <<= 1;
+  for (;;) {  // make the work list fit the workspace
+    int local = 0;
+    for (int b = tid; b < batch; b += 256) local += (max(seq_lens[b], 0) + chunk - 1) / chunk;
+    const int n = block_sum_256(local, red);
+    if (n <= capacity || chunk >= (1 << 24)) break;
+    chunk <<= 1;
+  }
+
+  // exclusive scan of per-request chunk counts; thread t owns a contiguous request segment
+  const int per = (batch + 255) / 256;
+  const int b0 = min(tid * per, batch), b1 = min(b0 + per, batch);
+  int mine = 0;
+  for (int b = b0; b < b1; ++b) mine += (max(seq_lens[b], 0) + chunk - 1) / chunk;
+  red[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int v = red[i];
+      red[i] = run;
+      run += v;
+    }
+    plan[0] = run;
+    plan[1] = chunk;
+    plan[2] = batch;
+    plan[3] = 0;
+  }
+  __syncthreads();
+  int run = red[tid];
+  for (int b = b0; b < b1; ++b) {
+    const int n = (max(seq_lens[b], 0) + chunk - 1) / chunk;
+    item_start[b] = run;
+    n_chunks[b] = n;
+    for (int j = 0; j < n; ++j) {
+      items[2 * (run + j)] = b;
+      items[2 * (run + j) + 1] = j;
+    }
+    run += n;
+  }
+}
+
+// ------------------------------------------------------------------------------
+// partial attention
+// ------------------------------------------------------------------------------
+struct DecodeParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  const int* page_table;
+  const int* req_rows;
+  const int* seq_lens;
+  const int* plan;
+  uint16_t* out;
+  float* part_o;
+  float* part_ml;
+  int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
+  int max_bs, hq, hv, group;  // hv = virtual kv heads (hq / G), group = hq / real kv heads
+  float scale_log2;
+};
+
+struct Tile {
+  U4 k[4], v[4];
+};
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) {
+  constexpr int D = 128;
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 4;  // DPP row = token sub-slot
+  const int c = lane & 15;  // 16-byte piece of the 256-B head row
+  const int gw = sgpr((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  const int nw = (int)gridDim.x * 4;
+  const int n_items = p.plan[0];
+  const int chunk = p.plan[1];
+  const int* item_start = p.plan + kPlanHdr;
+  const int* n_chunks = item_start + p.max_bs;
+  const int* items = n_chunks + p.max_bs;
+  const int total = n_items * p.hv;
+
+  for (int wi = gw; wi < total; wi += nw) {
+    const int item = wi / p.hv;
+    const int h = wi - item * p.hv;
+    const int b = sgpr(items[2 * item]);
+    const int j = sgpr(items[2 * item + 1]);
+    const int S = sgpr(p.seq_lens[b]);
+    const int t0 = j * chunk;
+    const int t1 = min(S, t0 + chunk);
+    const int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
+    const int* pt = p.page_table + (int64_t)row * p.pt_stride;
+    const int hq0 = h * G;
+    const int kvh = hq0 / p.group;
+
+    uint32_t qr[G][4];
+    {
+      const uint16_t* qp = p.q + (int64_t)b * p.q_stride + (int64_t)hq0 * D + c * 8;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const U4 u = ldg16(qp + g * D);
+        qr[g][0] = u.x; qr[g][1] = u.y; qr[g][2] = u.z; qr[g][3] = u.w;
+      }
+    }
+    const uint16_t* kb = p.k + (int64_t)kvh * p.kv_stride_head + c * 8;
+    const uint16_t* vb = p.v + (int64_t)kvh * p.kv_stride_head + c * 8;
+
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      m[g] = kNegBig;
+      l[g] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
+    }
+
+    // slots of tokens tb+4r .. tb+4r+3; entries at or past t1 are never dereferenced
+    auto load_slots = [&](int tb) -> int4 {
+      int tq = tb + 4 * r;
+      if (tq >= t1) tq = tb;
+      int4 s = *reinterpret_cast<const int4*>(pt + tq);
+      if (tq + 1 >= t1) s.y = s.x;
+      if (tq + 2 >= t1) s.z = s.x;
+      if (tq + 3 >= t1) s.w = s.x;
+      return s;
+    };
+    auto load_tile = [&](const int4& s, Tile& t) {
+      const int sl[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t off = (int64_t)sl[i] * p.kv_stride_tok;
+        t.k[i] = ldg16(kb + off);
+        t.v[i] = ldg16(vb + off);
+      }
+    };
+    auto compute = [&](const Tile& t, int tb, auto masked_tag) {
+      constexpr bool kMasked = decltype(masked_tag)::value;
+      float s[G][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float a = Elem<T>::dot2(qr[g][0], t.k[i].x, 0.f);
+          a = Elem<T>::dot2(qr[g][1], t.k[i].y, a);
+          a = Elem<T>::dot2(qr[g][2], t.k[i].z, a);
+          a = Elem<T>::dot2(qr[g][3], t.k[i].w, a);
+          s[g][i] = a;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[g][i] = row16_sum(s[g][i]) * p.scale_log2;
+      }
+      if constexpr (kMasked) {
+        const int tq = tb + 4 * r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (tq + i >= t1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) s[g][i] = -INFINITY;
+          }
+        }
+      }
+      float alpha[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float mx = fmaxf(fmaxf(m[g], fmaxf(s[g][0], s[g][1])), fmaxf(s[g][2], s[g][3]));
+        alpha[g] = __builtin_amdgcn_exp2f(m[g] - mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s[g][i] = __builtin_amdgcn_exp2f(s[g][i] - mx);
+          sum += s[g][i];
+        }
+        l[g] = fmaf(l[g], alpha[g], sum);
+        m[g] = mx;
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] *= alpha[g];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float vf[8] = {Elem<T>::lo(t.v[i].x), Elem<T>::hi(t.v[i].x), Elem<T>::lo(t.v[i].y),
+                             Elem<T>::hi(t.v[i].y), Elem<T>::lo(t.v[i].z), Elem<T>::hi(t.v[i].z),
+                             Elem<T>::lo(t.v[i].w), Elem<T>::hi(t.v[i].w)};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[g][e] = fmaf(s[g][i], vf[e], o[g][e]);
+        }
+      }
+    };
+    using Full = std::integral_constant<bool, false>;
+    using Masked = std::integral_constant<bool, true>;
+
+    const int ntiles = (t1 - t0 + 15) >> 4;
+    const int last = t0 + (ntiles - 1) * 16;
+    Tile A, B;
+    int4 sA = load_slots(t0);
+    load_tile(sA, A);
+    int4 sB = load_slots(min(t0 + 16, last));
+    int tix = 0;
+    // steady state: tiles tix and tix+1 are full (tix+2 exists), no branches inside
+    for (; tix + 2 < ntiles; tix += 2) {
+      const int tb = t0 + tix * 16;
+      load_tile(sB, B);
+      sA = load_slots(tb + 32);
+      compute(A, tb, Full{});
+      load_tile(sA, A);
+      sB = load_slots(min(tb + 48, last));
+      compute(B, tb + 16, Full{});
+    }
+    {  // one or two tiles left; A holds tile tix
+      const int tb = t0 + tix * 16;
+      const bool two = tix + 1 < ntiles;
+      if (two) {
+        load_tile(sB, B);
+        compute(A, tb, Full{});
+        compute(B, tb + 16, Masked{});
+      } else {
+        compute(A, tb, Masked{});
+      }
+    }
+
+    // merge the four DPP rows (disjoint token subsets) -> every lane holds the unit's state
+#pragma unroll
+    for (int step = 16; step <= 32; step <<= 1) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float m2 = __shfl_xor(m[g], step, 64);
+        const float l2 = __shfl_xor(l[g], step, 64);
+        const float mx = fmaxf(m[g], m2);
+        const float a1 = __builtin_amdgcn_exp2f(m[g] - mx);
+        const float a2 = __builtin_amdgcn_exp2f(m2 - mx);
+        l[g] = l[g] * a1 + l2 * a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float o2 = __shfl_xor(o[g][e], step, 64);
+          o[g][e] = o[g][e] * a1 + o2 * a2;
+        }
+        m[g] = mx;
+      }
+    }
+
+    const bool single = sgpr(n_chunks[b]) == 1;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if ((g & 3) != r) continue;  // spread the G head rows over the four DPP rows
+      const int hq = hq0 + g;
+      if (single) {
+        const float inv = 1.0f / l[g];
+        U4 u;
+        u.x = Elem<T>::pack(o[g][0] * inv, o[g][1] * inv);
+        u.y = Elem<T>::pack(o[g][2] * inv, o[g][3] * inv);
+        u.z = Elem<T>::pack(o[g][4] * inv, o[g][5] * inv);
+        u.w = Elem<T>::pack(o[g][6] * inv, o[g][7] * inv);
+        stg16(p.out + (int64_t)b * p.out_stride + (int64_t)hq * D + c * 8, u);
+      } else {
+        float* po = p.part_o + ((int64_t)item * p.hq + hq) * D + c * 8;
+        *reinterpret_cast<float4*>(po) = make_float4(o[g][0], o[g][1], o[g][2], o[g][3]);
+        *reinterpret_cast<float4*>(po + 4) = make_float4(o[g][4], o[g][5], o[g][6], o[g][7]);
+        if (c == 0) {
+          float* pm = p.part_ml + ((int64_t)item * p.hq + hq) * 2;
+          *reinterpret_cast<float2*>(pm) = make_float2(m[g], l[g]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// merge split-KV partials: one wave per (request, q head), 2 output dims per lane
+// ------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int batch) {
+  constexpr int D = 128;
+  const int lane = threadIdx.x & 63;
+  const int w = sgpr((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  if (w >= batch * p.hq) return;
+  const int b = w / p.hq;
+  const int hq = w - b * p.hq;
+  const int* item_start = p.plan + kPlanHdr;
+  const int* n_chunks = item_start + p.max_bs;
+  const int n = sgpr(n_chunks[b]);
+  if (n <= 1) return;  // single-chunk requests were finished by the attention kernel
+  const int i0 = sgpr(item_start[b]);
+  float mx = kNegBig;
+  for (int j = 0; j < n; ++j) mx = fmaxf(mx, p.part_ml[((int64_t)(i0 + j) * p.hq + hq) * 2]);
+  float acc0 = 0.f, acc1 = 0.f, den = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const int64_t base = (int64_t)(i0 + j) * p.hq + hq;
+    const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + base * 2);
+    const float wgt = __builtin_amdgcn_exp2f(ml.x - mx);
+    const float2 o = *reinterpret_cast<const float2*>(p.part_o + base * D + lane * 2);
+    acc0 = fmaf(wgt, o.x, acc0);
+    acc1 = fmaf(wgt, o.y, acc1);
+    den = fmaf(wgt, ml.y, den);
+  }
+  const float inv = 1.0f / den;
+  uint32_t* op = reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + (int64_t)hq * D) + lane;
+  *op = Elem<T>::pack(acc0 * inv, acc1 * inv);
+}
+
+template <typename T, int G>
+static int launch_decode(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+  static int blocks_per_cu = 0;
+  if (blocks_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G>, 256, 0) != hipSuccess ||
+        nb <= 0) {
+      (void)hipGetLastError();
+      nb = 2;
+    }
+    blocks_per_cu = nb;
+  }
+  const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+  const int64_t max_units = (int64_t)capacity * p.hv;
+  int64_t blocks = (max_units + 3) / 4;
+  const int64_t resident = (int64_t)cus * blocks_per_cu;
+  if (blocks > resident) blocks = resident;
+  if (blocks < 1) blocks = 1;
+  attn_decode_kernel<T, G><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
+  attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
+  return MSGL_OK;
+}
+
+template <typename T>
+static int dispatch_group(int G, const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+  switch (G) {
+    case 1: return launch_decode<T, 1>(p, batch, capacity, s);
+    case 2: return launch_decode<T, 2>(p, batch, capacity, s);
+    case 3: return launch_decode<T, 3>(p, batch, capacity, s);
+    case 4: return launch_decode<T, 4>(p, batch, capacity, s);
+    case 5: return launch_decode<T, 5>(p, batch, capacity, s);
+    case 6: return launch_decode<T, 6>(p, batch, capacity, s);
+    case 7: return launch_decode<T, 7>(p, batch, capacity, s);
+    case 8: return launch_decode<T, 8>(p, batch, capacity, s);
+  }
+  set_error("attn_decode: unsupported heads-per-unit %d", G);
+  return MSGL_EINVAL;
+}
+
+// heads packed per work unit: the whole GQA group when it is <= 8, else its largest divisor <= 8
+static int heads_per_unit(int group) {
+  if (group <= 8) return group;
+  for (int g = 8; g >= 1; --g)
+    if (group % g == 0) return g;
+  return 1;
+}
+
+static int decode_oversub() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("MSGL_DECODE_OVERSUB");
+    v = e ? atoi(e) : 4;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+
+}  // namespace msgl
+
+using namespace msgl;
+
+extern "C" int64_t msgl_attn_decode_plan_words(int max_bs, int capacity) {
+  if (max_bs < 1 || capacity < max_bs) return MSGL_EINVAL;
+  return (int64_t)kPlanHdr + 2ll * max_bs + 2ll * capacity;
+}
+
+extern "C" int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim) {
+  if (capacity < 1 || num_q_heads < 1 || head_dim < 1) return MSGL_EINVAL;
+  return (int64_t)capacity * num_q_heads * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int msgl_attn_decode_plan(int32_t* plan, const int32_t* seq_lens, int batch, int max_bs,
+                                     int capacity, int num_kv_heads, int min_chunk, void* stream) {
+  MSGL_REQUIRE(plan && seq_lens, "attn_decode_plan: null pointer");
+  MSGL_REQUIRE(batch >= 1 && batch <= max_bs, "attn_decode_plan: batch %d outside [1, %d]", batch, max_bs);
+  MSGL_REQUIRE(capacity >= max_bs, "attn_decode_plan: capacity %d < max_bs %d", capacity, max_bs);
+  MSGL_REQUIRE(num_kv_heads >= 1, "attn_decode_plan: bad head count");
+  if (min_chunk <= 0) min_chunk = 64;
+  MSGL_REQUIRE(min_chunk % 16 == 0 && (min_chunk & (min_chunk - 1)) == 0,
+               "attn_decode_plan: min_chunk %d must be a power of two >= 16", min_chunk);
+  const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+  // aim at oversub x (8 waves per CU) work units in total
+  int target = (int)(((int64_t)cus * 8 * decode_oversub()) / num_kv_heads);
+  if (target < 1) target = 1;
+  decode_plan_kernel<<<dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
+      plan, seq_lens, batch, max_bs, capacity, target, min_chunk);
+  MSGL_CHECK_LAUNCH("attn_decode_plan");
+  return MSGL_OK;
+}
+
+extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
+                                const int32_t* seq_lens, const int32_t* plan, void* workspace, int batch,
+                                int max_bs, int capacity, int num_q_heads, int num_kv_heads, int head_dim,
+                                int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
+                                int64_t out_stride_tok, float sm_scale, int dtype, void* stream) {
+  MSGL_REQUIRE(out && q && k_cache && v_cache && page_table && seq_lens && plan && workspace,
+               "attn_decode: null pointer");
+  MSGL_REQUIRE(batch >= 1 && batch <= max_bs && capacity >= max_bs, "attn_decode: bad batch/capacity");
+  MSGL_REQUIRE(head_dim == 128, "attn_decode: head_dim %d unsupported (128 only)", head_dim);
+  MSGL_REQUIRE(num_kv_heads >= 1 && num_q_heads % num_kv_heads == 0, "attn_decode: %d q heads / %d kv heads",
+               num_q_heads, num_kv_heads);
+  MSGL_REQUIRE(pt_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(page_table) & 15u) == 0,
+               "attn_decode: page table rows must be 16-byte aligned");
+  MSGL_REQUIRE(q_stride_tok % 8 == 0 && kv_stride_tok % 8 == 0 && kv_stride_head % 8 == 0 &&
+                   out_stride_tok % 8 == 0,
+               "attn_decode: strides must be multiples of 8 elements");
+  MSGL_REQUIRE(aligned16(out) && aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace),
+               "attn_decode: pointers must be 16-byte aligned");
+  const int group = num_q_heads / num_kv_heads;
+  const int G = heads_per_unit(group);
+  DecodeParams p;
+  p.q = (const uint16_t*)q;
+  p.k = (const uint16_t*)k_cache;
+  p.v = (const uint16_t*)v_cache;
+  p.page_table = page_table;
+  p.req_rows = req_rows;
+  p.seq_lens = seq_lens;
+  p.plan = plan;
+  p.out = (uint16_t*)out;
+  p.part_o = (float*)workspace;
+  p.part_ml = p.part_o + (int64_t)capacity * num_q_heads * head_dim;
+  p.pt_stride = pt_stride;
+  p.q_stride = q_stride_tok;
+  p.kv_stride_tok = kv_stride_tok;
+  p.kv_stride_head = kv_stride_head;
+  p.out_stride = out_stride_tok;
+  p.max_bs = max_bs;
+  p.hq = num_q_heads;
+  p.hv = num_q_heads / G;
+  p.group = group;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (dtype == MSGL_BF16) rc = dispatch_group<BF16>(G, p, batch, capacity, s);
+  else if (dtype == MSGL_FP16) rc = dispatch_group<FP16>(G, p, batch, capacity, s);
+  else {
+    set_error("attn_decode: unsupported dtype code %d", dtype);
+    return MSGL_EINVAL;
+  }
+  if (rc != MSGL_OK) return rc;
+  MSGL_CHECK_LAUNCH("attn_decode");
+  return MSGL_OK;
+}

@@ -1,0 +1,136 @@
+// Shared device/host helpers for the gfx950 kernels.  wave = 64 lanes, hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/msgl_hip.h"
+
+namespace msgl {
+
+constexpr int kWave = 64;
+
+// ---- host-side error plumbing -------------------------------------------------
+void set_error(const char* fmt, ...);  // defined in host.cpp
+
+#define MSGL_REQUIRE(cond, ...)       \
+  do {                                \
+    if (!(cond)) {                    \
+      ::msgl::set_error(__VA_ARGS__); \
+      return MSGL_EINVAL;             \
+    }                                 \
+  } while (0)
+
+#define MSGL_CHECK_LAUNCH(name)                                          \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      ::msgl::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return MSGL_ELAUNCH;                                               \
+    }                                                                    \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int device_cu_count();  // cached, host.cpp
+
+// ---- 16-bit float element traits ---------------------------------------------
+struct BF16 {};  // storage: uint16_t, upper half of an fp32
+struct FP16 {};  // storage: IEEE half
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_v;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_v;
+
+template <typename T>
+struct Elem;
+
+template <>
+struct Elem<BF16> {
+  // unpack the two 16-bit halves of a dword to fp32 (exact)
+  static __device__ __forceinline__ float lo(uint32_t u) { return __uint_as_float(u << 16); }
+  static __device__ __forceinline__ float hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+  // round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet)
+  static __device__ __forceinline__ uint32_t bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return bits(a) | (bits(b) << 16); }
+  // acc += a.lo*b.lo + a.hi*b.hi  (fp32 accumulate, v_dot2c_f32_bf16)
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, a),
+                                           __builtin_bit_cast(bf16x2_v, b), acc, false);
+  }
+};
+
+template <>
+struct Elem<FP16> {
+  static __device__ __forceinline__ float lo(uint32_t u) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu));
+  }
+  static __device__ __forceinline__ float hi(uint32_t u) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+  }
+  static __device__ __forceinline__ uint32_t bits(float f) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return bits(a) | (bits(b) << 16); }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_v, a), __builtin_bit_cast(f16x2_v, b), acc,
+                                  false);
+  }
+};
+
+// ---- cross-lane helpers (DPP: full-rate, no LDS) -------------------------------
+// dpp_ctrl encodings (gfx9): quad_perm = 0x00..0xff, row_shr:n = 0x110+n,
+// row_ror:n = 0x120+n, row_mirror = 0x140, row_half_mirror = 0x141.
+template <int kCtrl>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), kCtrl, 0xf, 0xf, false));
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // i -> 7-i  within each 8 lanes
+constexpr int kDppRowMirror = 0x140;   // i -> 15-i within each 16 lanes
+
+// all-reduce (sum) over each aligned group of 8 / 16 lanes
+__device__ __forceinline__ float row8_sum(float x) {
+  x += dpp_mov<kDppXor1>(x);
+  x += dpp_mov<kDppXor2>(x);
+  x += dpp_mov<kDppHalfMirror>(x);
+  return x;
+}
+__device__ __forceinline__ float row16_sum(float x) {
+  x = row8_sum(x);
+  x += dpp_mov<kDppRowMirror>(x);
+  return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+  x = row16_sum(x);
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+  x = fmaxf(x, dpp_mov<kDppXor1>(x));
+  x = fmaxf(x, dpp_mov<kDppXor2>(x));
+  x = fmaxf(x, dpp_mov<kDppHalfMirror>(x));
+  x = fmaxf(x, dpp_mov<kDppRowMirror>(x));
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  x = fmaxf(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+
+__device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// 16-byte vector used for every wide load/store
+struct __attribute__((aligned(16))) U4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 ldg16(const void* p) { return *reinterpret_cast<const U4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
+
+}  // namespace msgl

@@ -1,0 +1,129 @@
+"""Mirror of the flashinfer functions the reference binds on the dense path.
+
+The reference reaches flashinfer through attributes bound in constructors
+(P/layers/norm.py:10-30, P/layers/rotary.py:35-37) and lazy imports
+(P/layers/activation.py:10,16, P/engine/sample.py:30); a module exposing the same names
+with the same argument meaning is a drop-in.  Everything forwards to
+the hand-written gfx950 kernels via ops.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional
+
+import torch
+
+from . import ops
+
+
+# ---- norm (P/layers/norm.py:17,20,37) -----------------------------------------------------
+def rmsnorm(input: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
+            out: Optional[torch.Tensor] = None, enable_pdl: Optional[bool] = None) -> torch.Tensor:
+    return ops.rmsnorm(input, weight, eps, out=out)
+
+
+def fused_add_rmsnorm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
+                      enable_pdl: Optional[bool] = None) -> None:
+    ops.fused_add_rmsnorm(input, residual, weight, eps)
+
+
+# ---- rope (P/layers/rotary.py:45-51) ------------------------------------------------------
+def apply_rope_with_cos_sin_cache_inplace(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                                          head_size: int, cos_sin_cache: torch.Tensor,
+                                          is_neox: bool = True) -> None:
+    if not is_neox:
+        raise NotImplementedError("only NeoX (rotate-half) RoPE is on the reference's path")
+    ops.rope_neox_inplace(positions, query, key, head_size, cos_sin_cache)
+
+
+def build_cos_sin_cache(rotary_dim: int, max_position: int, base: float,
+                        rope_scaling: Optional[Dict[str, Any]] = None,
+                        device: torch.device | str = "cpu") -> torch.Tensor:
+    """fp32 [max_position, rotary_dim] = cat(cos, sin); same construction (and therefore the
+    same bits on CPU) as RotaryEmbedding.__init__ / _get_rope (P/layers/rotary.py:24-32,
+    55-114): default, llama3 and yarn inverse-frequency post-processing."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
+    kind = None if rope_scaling is None else rope_scaling.get("rope_type", "default")
+    if kind == "llama3":
+        factor = rope_scaling["factor"]
+        low, high = rope_scaling["low_freq_factor"], rope_scaling["high_freq_factor"]
+        orig = rope_scaling["original_max_position_embeddings"]
+        wave_len = 2 * math.pi / inv_freq
+        if low == high:
+            inv_freq = torch.where(wave_len < orig / high, inv_freq, inv_freq / factor)
+        else:
+            smooth = torch.clamp((orig / wave_len - low) / (high - low), 0, 1)
+            inv_freq = ((1 - smooth) / factor + smooth) * inv_freq
+    elif kind == "yarn":
+        factor = rope_scaling["factor"]
+        beta_fast = rope_scaling.get("beta_fast", 32.0)
+        beta_slow = rope_scaling.get("beta_slow", 1.0)
+        orig = rope_scaling["original_max_position_embeddings"]
+
+        def corr_dim(rotations: float) -> float:
+            return rotary_dim * math.log(orig / (rotations * 2 * math.pi)) / (2 * math.log(base))
+
+        lo = max(math.floor(corr_dim(beta_fast)), 0)
+        hi = min(math.ceil(corr_dim(beta_slow)), rotary_dim // 2 - 1)
+        ramp = torch.clamp((torch.arange(rotary_dim // 2, dtype=torch.float32) - lo) / max(hi - lo, 1), 0, 1)
+        inv_freq = (inv_freq / factor) * ramp + inv_freq * (1 - ramp)
+    elif kind not in (None, "default"):
+        raise ValueError(f"Unsupported rope_scaling = {rope_scaling}")
+    t = torch.arange(max_position, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(device)
+
+
+# ---- activation (P/layers/activation.py:9-18) ---------------------------------------------
+def silu_and_mul(input: torch.Tensor, out: Optional[torch.Tensor] = None,
+                 enable_pdl: Optional[bool] = None) -> torch.Tensor:
+    return ops.silu_and_mul(input, out=out)
+
+
+def gelu_and_mul(input: torch.Tensor, out: Optional[torch.Tensor] = None,
+                 enable_pdl: Optional[bool] = None) -> torch.Tensor:
+    raise NotImplementedError("gelu_and_mul: no dense model in scope uses it (SURVEY.md section 8)")
+
+
+# ---- sampling (P/engine/sample.py:30-45) --------------------------------------------------
+class _SamplingNamespace:
+    """`import flashinfer.sampling as sampling` surface."""
+
+    def __init__(self) -> None:
+        self._offset = 0
+
+    def _next_offset(self, rows: int) -> int:
+        off = self._offset
+        self._offset += rows
+        return off
+
+    @staticmethod
+    def softmax(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None,
+                enable_pdl: Optional[bool] = None) -> torch.Tensor:
+        if temperature is None:
+            temperature = torch.ones(logits.shape[0], dtype=torch.float32, device=logits.device)
+        return ops.softmax_temperature(logits, temperature)
+
+    def _sample(self, probs, top_k, top_p):
+        dev = probs.device
+        if isinstance(top_k, int):
+            top_k = torch.full((probs.shape[0],), top_k, dtype=torch.int32, device=dev)
+        if isinstance(top_p, float):
+            top_p = torch.full((probs.shape[0],), top_p, dtype=torch.float32, device=dev)
+        # every TP rank seeds identically (P/engine/engine.py:37) => identical draws on all ranks
+        return ops.sample_top_k_top_p(probs, top_k, top_p, torch.initial_seed(), self._next_offset(probs.shape[0]))
+
+    def sampling_from_probs(self, probs, **_kw):
+        return self._sample(probs, None, None)
+
+    def top_k_sampling_from_probs(self, probs, top_k, **_kw):
+        return self._sample(probs, top_k, None)
+
+    def top_p_sampling_from_probs(self, probs, top_p, **_kw):
+        return self._sample(probs, None, top_p)
+
+    def top_k_top_p_sampling_from_probs(self, probs, top_k, top_p, **_kw):
+        return self._sample(probs, top_k, top_p)
+
+
+sampling = _SamplingNamespace()

@@ -1,0 +1,311 @@
+"""torch-facing wrappers over the C-ABI (include/msgl_hip.h).
+
+PyTorch is used for device memory and streams only: each wrapper validates what the C
+side cannot see (device, dtype), passes raw pointers / strides / the current HIP stream
+through ctypes, and returns.  No wrapper allocates except where the mirrored reference
+function does (e.g. `indexing` output), none synchronises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    if t.dtype == torch.float16:
+        return _lib.FP16
+    raise TypeError(f"expected a bf16/fp16 tensor, got {t.dtype}")
+
+
+def _logits_dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.F32
+    return _dt(t)
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "mini_sglang_amd ops run on the HIP device only (got a CPU tensor); "
+                "there is no CPU fallback in the product path"
+            )
+
+
+def _is_i64(t: torch.Tensor) -> int:
+    if t.dtype == torch.int64:
+        return 1
+    if t.dtype == torch.int32:
+        return 0
+    raise TypeError(f"index tensor must be int32/int64, got {t.dtype}")
+
+
+# ---------------------------------------------------------------------------- store / gather
+def store_kv(k_cache: torch.Tensor, v_cache: torch.Tensor, indices: torch.Tensor, k: torch.Tensor,
+             v: torch.Tensor) -> None:
+    """k_cache[indices] = k; v_cache[indices] = v over rows of `row` elements.
+
+    k_cache/v_cache: [slots, row] views (row stride free), k/v: [T, row] views (row stride
+    free, e.g. slices of the fused qkv tensor).  Reference: C/jit/store.cu:59-121.
+    """
+    _need_cuda(k_cache, v_cache, indices, k, v)
+    assert k_cache.dim() == 2 and v_cache.dim() == 2 and k.dim() == 2 and v.dim() == 2
+    assert k_cache.shape[1] == k.shape[1] == v.shape[1] == v_cache.shape[1]
+    assert k_cache.stride(1) == v_cache.stride(1) == k.stride(1) == v.stride(1) == 1
+    assert k_cache.dtype == v_cache.dtype == k.dtype == v.dtype
+    assert k_cache.stride(0) == v_cache.stride(0)
+    assert indices.dim() == 1 and indices.shape[0] == k.shape[0] == v.shape[0] and indices.is_contiguous()
+    es = k.element_size()
+    check(
+        lib().msgl_store_kv(
+            k_cache.data_ptr(), v_cache.data_ptr(), indices.data_ptr(), _is_i64(indices), k.data_ptr(),
+            v.data_ptr(), k.shape[0], k.shape[1] * es, k_cache.stride(0) * es, k.stride(0) * es,
+            v.stride(0) * es, _stream(),
+        ),
+        "store_kv",
+    )
+
+
+def embedding_gather(weight: torch.Tensor, indices: torch.Tensor, out: Optional[torch.Tensor] = None,
+                     vocab_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    _need_cuda(weight, indices)
+    assert weight.dim() == 2 and weight.is_contiguous() and indices.dim() == 1 and indices.is_contiguous()
+    if out is None:
+        out = weight.new_empty(indices.shape[0], weight.shape[1])
+    assert out.is_contiguous() and out.shape == (indices.shape[0], weight.shape[1]) and out.dtype == weight.dtype
+    start, length = vocab_range if vocab_range is not None else (0, 0)
+    check(
+        lib().msgl_embedding_gather(
+            out.data_ptr(), weight.data_ptr(), indices.data_ptr(), _is_i64(indices), indices.shape[0],
+            weight.shape[1] * weight.element_size(), 1 if vocab_range is not None else 0, start, length,
+            _stream(),
+        ),
+        "embedding_gather",
+    )
+    return out
+
+
+def fast_compare_key(x: torch.Tensor, y: torch.Tensor) -> int:
+    if not (x.dim() == 1 and y.dim() == 1 and x.is_contiguous() and y.is_contiguous() and x.device.type == "cpu"
+            and y.device.type == "cpu" and x.dtype in (torch.int32, torch.int64)):
+        raise RuntimeError("Both tensors must be 1D CPU int tensors.")
+    if x.dtype != y.dtype:
+        raise RuntimeError("fast_compare_key: dtype mismatch")
+    r = lib().msgl_fast_compare_key(x.data_ptr(), x.shape[0], y.data_ptr(), y.shape[0], x.element_size())
+    if r < 0:
+        check(int(r), "fast_compare_key")
+    return int(r)
+
+
+# ---------------------------------------------------------------------------- norm / rope / act
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x * rsqrt(mean(x^2) + eps) * w over the last dim of a 2-D or 3-D (strided) tensor."""
+    _need_cuda(x, weight)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    assert out.shape == x.shape and out.dtype == x.dtype == weight.dtype
+    assert x.stride(-1) == 1 and out.stride(-1) == 1 and weight.is_contiguous() and weight.shape[0] == x.shape[-1]
+    if x.dim() == 2:
+        n0, n1, xs0, xs1, os0, os1 = x.shape[0], 1, x.stride(0), 0, out.stride(0), 0
+    elif x.dim() == 3:
+        n0, n1, xs0, xs1, os0, os1 = x.shape[0], x.shape[1], x.stride(0), x.stride(1), out.stride(0), out.stride(1)
+    else:
+        raise ValueError("rmsnorm expects a 2-D or 3-D tensor")
+    check(
+        lib().msgl_rmsnorm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), float(eps), n0, n1, x.shape[-1],
+                           xs0, xs1, os0, os1, _dt(x), _stream()),
+        "rmsnorm",
+    )
+    return out
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+    _need_cuda(x, residual, weight)
+    assert x.dim() == 2 and x.shape == residual.shape and x.dtype == residual.dtype == weight.dtype
+    assert x.stride(1) == 1 and residual.stride(1) == 1 and weight.is_contiguous()
+    check(
+        lib().msgl_fused_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), float(eps), x.shape[0],
+                                     x.shape[1], x.stride(0), residual.stride(0), _dt(x), _stream()),
+        "fused_add_rmsnorm",
+    )
+
+
+def rope_neox_inplace(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                      cos_sin_cache: torch.Tensor) -> None:
+    _need_cuda(positions, query, key, cos_sin_cache)
+    assert query.dim() == 2 and key.dim() == 2 and query.stride(1) == 1 and key.stride(1) == 1
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous()
+    assert cos_sin_cache.shape[1] == head_size and positions.is_contiguous()
+    assert query.shape[1] % head_size == 0 and key.shape[1] % head_size == 0
+    check(
+        lib().msgl_rope_neox_inplace(
+            query.data_ptr(), key.data_ptr(), positions.data_ptr(), _is_i64(positions), cos_sin_cache.data_ptr(),
+            query.shape[0], query.shape[1] // head_size, key.shape[1] // head_size, head_size, query.stride(0),
+            key.stride(0), _dt(query), _stream(),
+        ),
+        "rope_neox_inplace",
+    )
+
+
+def qk_norm_rope_store(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_norm_w: Optional[torch.Tensor],
+                       k_norm_w: Optional[torch.Tensor], eps: float, positions: torch.Tensor,
+                       cos_sin_cache: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                       out_loc: torch.Tensor, head_dim: int) -> None:
+    """Fused qk-norm -> RoPE -> KV store over [T, H*D] row views q, k, v (see msgl_hip.h)."""
+    _need_cuda(q, k, v, positions, cos_sin_cache, k_cache, v_cache, out_loc)
+    assert q.dim() == 2 and k.dim() == 2 and v.dim() == 2 and k_cache.dim() == 2 and v_cache.dim() == 2
+    assert k.shape[1] == v.shape[1] == k_cache.shape[1] == v_cache.shape[1]
+    assert k_cache.stride(0) == v_cache.stride(0)
+    check(
+        lib().msgl_qk_norm_rope_store(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            q_norm_w.data_ptr() if q_norm_w is not None else None,
+            k_norm_w.data_ptr() if k_norm_w is not None else None, float(eps), positions.data_ptr(),
+            _is_i64(positions), cos_sin_cache.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+            out_loc.data_ptr(), _is_i64(out_loc), q.shape[0], q.shape[1] // head_dim, k.shape[1] // head_dim,
+            head_dim, q.stride(0), k.stride(0), v.stride(0), k_cache.stride(0), _dt(q), _stream(),
+        ),
+        "qk_norm_rope_store",
+    )
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 2 == 0
+    d = x.shape[1] // 2
+    if out is None:
+        out = torch.empty((x.shape[0], d), dtype=x.dtype, device=x.device)
+    assert out.shape == (x.shape[0], d) and out.stride(1) == 1 and out.dtype == x.dtype
+    check(
+        lib().msgl_silu_and_mul(out.data_ptr(), x.data_ptr(), x.shape[0], d, x.stride(0), out.stride(0), _dt(x),
+                                _stream()),
+        "silu_and_mul",
+    )
+    return out
+
+
+# ---------------------------------------------------------------------------- attention
+def attn_decode_plan_words(max_bs: int, capacity: int) -> int:
+    n = lib().msgl_attn_decode_plan_words(max_bs, capacity)
+    check(int(n), "attn_decode_plan_words")
+    return int(n)
+
+
+def attn_decode_workspace_bytes(capacity: int, num_q_heads: int, head_dim: int) -> int:
+    n = lib().msgl_attn_decode_workspace_bytes(capacity, num_q_heads, head_dim)
+    check(int(n), "attn_decode_workspace_bytes")
+    return int(n)
+
+
+def attn_decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, batch: int, max_bs: int, capacity: int,
+                     num_kv_heads: int, min_chunk: int = 64) -> None:
+    _need_cuda(plan, seq_lens)
+    assert plan.dtype == torch.int32 and seq_lens.dtype == torch.int32 and seq_lens.is_contiguous()
+    assert plan.numel() >= attn_decode_plan_words(max_bs, capacity) and seq_lens.numel() >= batch
+    check(
+        lib().msgl_attn_decode_plan(plan.data_ptr(), seq_lens.data_ptr(), batch, max_bs, capacity, num_kv_heads,
+                                    min_chunk, _stream()),
+        "attn_decode_plan",
+    )
+
+
+def attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                page_table: torch.Tensor, req_rows: Optional[torch.Tensor], seq_lens: torch.Tensor,
+                plan: torch.Tensor, workspace: torch.Tensor, batch: int, max_bs: int, capacity: int,
+                sm_scale: float) -> None:
+    """q: [B, Hq, D] (token stride free), k_cache/v_cache: [slots, Hkv, D], out: [B, Hq, D]."""
+    _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, plan, workspace)
+    assert q.dim() == 3 and k_cache.dim() == 3 and out.dim() == 3
+    hq, d = q.shape[1], q.shape[2]
+    hkv = k_cache.shape[1]
+    assert q.stride(2) == 1 and q.stride(1) == d and out.stride(2) == 1 and out.stride(1) == d
+    assert k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride() and v_cache.shape == k_cache.shape
+    assert page_table.dtype == torch.int32 and page_table.dim() == 2 and page_table.stride(1) == 1
+    assert q.dtype == k_cache.dtype == v_cache.dtype == out.dtype
+    check(
+        lib().msgl_attn_decode(
+            out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), page_table.data_ptr(),
+            page_table.stride(0), req_rows.data_ptr() if req_rows is not None else None, seq_lens.data_ptr(),
+            plan.data_ptr(), workspace.data_ptr(), batch, max_bs, capacity, hq, hkv, d, q.stride(0),
+            k_cache.stride(0), k_cache.stride(1), out.stride(0), float(sm_scale), _dt(q), _stream(),
+        ),
+        "attn_decode",
+    )
+
+
+def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                 page_table: torch.Tensor, req_rows: Optional[torch.Tensor], seq_lens: torch.Tensor,
+                 cu_seqlens_q: torch.Tensor, tile_cu: torch.Tensor, batch: int, total_tiles: int,
+                 sm_scale: float) -> None:
+    _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, cu_seqlens_q, tile_cu)
+    hq, d = q.shape[1], q.shape[2]
+    hkv = k_cache.shape[1]
+    assert q.stride(2) == 1 and q.stride(1) == d and out.stride(2) == 1 and out.stride(1) == d
+    assert k_cache.stride(2) == 1 and v_cache.stride() == k_cache.stride()
+    assert page_table.dtype == torch.int32 and page_table.stride(1) == 1
+    check(
+        lib().msgl_attn_prefill(
+            out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), page_table.data_ptr(),
+            page_table.stride(0), req_rows.data_ptr() if req_rows is not None else None, seq_lens.data_ptr(),
+            cu_seqlens_q.data_ptr(), tile_cu.data_ptr(), batch, total_tiles, hq, hkv, d, q.stride(0),
+            k_cache.stride(0), k_cache.stride(1), out.stride(0), float(sm_scale), _dt(q), _stream(),
+        ),
+        "attn_prefill",
+    )
+
+
+# ---------------------------------------------------------------------------- sampling
+def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(logits)
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    if out is None:
+        out = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    check(
+        lib().msgl_argmax_rows(out.data_ptr(), logits.data_ptr(), logits.shape[0], logits.shape[1],
+                               logits.stride(0), _logits_dt(logits), _stream()),
+        "argmax_rows",
+    )
+    return out
+
+
+def softmax_temperature(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
+    _need_cuda(logits, temperatures)
+    assert logits.dim() == 2 and logits.stride(1) == 1 and temperatures.dtype == torch.float32
+    probs = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    check(
+        lib().msgl_softmax_temperature(probs.data_ptr(), logits.data_ptr(), temperatures.data_ptr(),
+                                       logits.shape[0], logits.shape[1], logits.stride(0), probs.stride(0),
+                                       _logits_dt(logits), _stream()),
+        "softmax_temperature",
+    )
+    return probs
+
+
+def sample_top_k_top_p(probs: torch.Tensor, top_k: Optional[torch.Tensor], top_p: Optional[torch.Tensor],
+                       seed: int, offset: int) -> torch.Tensor:
+    _need_cuda(probs)
+    assert probs.dim() == 2 and probs.stride(1) == 1 and probs.dtype == torch.float32
+    out = torch.empty(probs.shape[0], dtype=torch.int32, device=probs.device)
+    if top_k is not None:
+        assert top_k.dtype == torch.int32 and top_k.is_cuda and top_k.numel() == probs.shape[0]
+    if top_p is not None:
+        assert top_p.dtype == torch.float32 and top_p.is_cuda and top_p.numel() == probs.shape[0]
+    check(
+        lib().msgl_sample_top_k_top_p(
+            out.data_ptr(), probs.data_ptr(), top_k.data_ptr() if top_k is not None else None,
+            top_p.data_ptr() if top_p is not None else None, probs.shape[0], probs.shape[1], probs.stride(0),
+            seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, _stream(),
+        ),
+        "sample_top_k_top_p",
+    )
+    return out

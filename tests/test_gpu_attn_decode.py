@@ -1,0 +1,197 @@
+"""GPU parity: paged decode attention vs the CPU oracle (Appendix B "paged attention").
+
+Synthetic page tables as SURVEY.md section 7 step 3 asks: randomly permuted token slots,
+ragged lengths, dummy-page padding rows, table tails holding stale (even invalid) slots
+that must never be dereferenced, q as a strided view of a fused qkv tensor.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(atol=6e-3, rtol=2 ** -7)  # 2 bf16 ulp on O(1) outputs
+
+
+def make_case(g, B, hq, hkv, lens, page_size, dtype=torch.bfloat16, max_seq=None, poison_tail=True):
+    D = 128
+    max_seq = max_seq or ((max(lens) + 31) // 32 * 32)
+    n_rows = B + 3
+    pages_per_req = (max_seq + page_size - 1) // page_size
+    n_pages = n_rows * pages_per_req + 2  # + dummy page (valid data) + poison page (NaN)
+    slots = n_pages * page_size
+    k_cache = torch.randn((slots, hkv, D), generator=g).to(dtype)
+    v_cache = torch.randn((slots, hkv, D), generator=g).to(dtype)
+    poison = (n_pages - 1) * page_size
+    k_cache[poison:] = float("nan")
+    v_cache[poison:] = float("nan")
+    perm = torch.randperm(n_pages - 2, generator=g)
+    table = torch.zeros((n_rows, max_seq), dtype=torch.int32)
+    rows = torch.randperm(n_rows, generator=g)[:B].tolist()
+    p = 0
+    for b, row in enumerate(rows):
+        need = (lens[b] + page_size - 1) // page_size
+        pg = perm[p: p + need].to(torch.int32) * page_size
+        p += need
+        tok = (pg.unsqueeze(1) + torch.arange(page_size, dtype=torch.int32)).flatten()
+        n = min(need * page_size, max_seq)
+        table[row, :n] = tok[:n]
+        if poison_tail and lens[b] < max_seq:
+            # stale entries beyond the sequence must never be dereferenced: they point at NaN rows
+            table[row, lens[b]:] = poison
+    qkv = torch.randn((B, (hq + 2 * hkv) * D), generator=g).to(dtype)
+    return dict(k=k_cache, v=v_cache, table=table, rows=rows, lens=lens, qkv=qkv, hq=hq, hkv=hkv, D=D)
+
+
+def run_decode(ops, dev, case, max_bs=None, capacity=None, min_chunk=64):
+    B, hq, hkv, D = len(case["lens"]), case["hq"], case["hkv"], case["D"]
+    max_bs = max_bs or B
+    capacity = capacity or max(4 * max_bs, 1024)
+    qkv = case["qkv"].to(dev)
+    q = qkv[:, : hq * D].view(B, hq, D)
+    out = torch.empty((B, hq, D), dtype=qkv.dtype, device=dev)
+    plan = torch.zeros(ops.attn_decode_plan_words(max_bs, capacity), dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.attn_decode_workspace_bytes(capacity, hq, D), dtype=torch.uint8, device=dev)
+    seq = torch.tensor(case["lens"], dtype=torch.int32, device=dev)
+    rows = torch.tensor(case["rows"], dtype=torch.int32, device=dev)
+    ops.attn_decode_plan(plan, seq, B, max_bs, capacity, hkv, min_chunk)
+    ops.attn_decode(out, q, case["k"].to(dev), case["v"].to(dev), case["table"].to(dev), rows, seq, plan, ws, B,
+                    max_bs, capacity, 1.0 / math.sqrt(D))
+    torch.cuda.synchronize()
+    return out.cpu(), plan.cpu()
+
+
+def oracle(case):
+    B, hq, D = len(case["lens"]), case["hq"], case["D"]
+    q = case["qkv"][:, : hq * D].reshape(B, hq, D)
+    table = case["table"].clone()
+    return ref_ops.paged_attention_ref(q, case["k"], case["v"], table, case["rows"], case["lens"], [1] * B,
+                                       1.0 / math.sqrt(D), double=True)
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from mini_sglang_amd import ops as _ops
+
+    return _ops
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (40, 8), (64, 8), (8, 8), (32, 8), (5, 1), (8, 1), (10, 2), (24, 8),
+                                    (28, 4), (48, 8), (16, 1)])
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_decode_matches_oracle_groups(ops, dev, hq, hkv, page_size):
+    g = torch.Generator().manual_seed(hq * 100 + hkv + page_size)
+    lens = [1, 2, 15, 16, 17, 63, 64, 65, 200, 777, 1024, 33]
+    case = make_case(g, len(lens), hq, hkv, lens, page_size)
+    out, plan = run_decode(ops, dev, case)
+    ref = oracle(case)
+    assert torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out.double(), ref, **TOL)
+
+
+@pytest.mark.parametrize("min_chunk", [16, 64, 256])
+def test_decode_split_kv_chunks(ops, dev, min_chunk):
+    """Long and short requests mixed: multi-chunk merge and single-chunk direct write."""
+    g = torch.Generator().manual_seed(min_chunk)
+    lens = [3000, 5, 1, 2047, 2048, 2049, 300, 17]
+    case = make_case(g, len(lens), 40, 8, lens, 1)
+    out, plan = run_decode(ops, dev, case, min_chunk=min_chunk)
+    n_items, chunk = int(plan[0]), int(plan[1])
+    assert n_items == sum((n + chunk - 1) // chunk for n in lens)
+    assert chunk >= min_chunk
+    torch.testing.assert_close(out.double(), oracle(case), **TOL)
+
+
+def test_decode_plan_respects_capacity(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    lens = [4000] * 6 + [1, 9]
+    case = make_case(g, len(lens), 16, 8, lens, 1)
+    out, plan = run_decode(ops, dev, case, max_bs=16, capacity=16, min_chunk=16)
+    assert int(plan[0]) <= 16
+    torch.testing.assert_close(out.double(), oracle(case), **TOL)
+
+
+def test_decode_padded_dummy_rows(ops, dev):
+    """Graph padding (P/engine/graph.py:160-166): rows of the dummy request have length 1
+    and all point at the dummy slot; they must not disturb real rows."""
+    g = torch.Generator().manual_seed(9)
+    lens = [120, 1, 1, 1, 64, 1, 1, 1]
+    case = make_case(g, len(lens), 40, 8, lens, 1)
+    dummy_row, dummy_slot = case["rows"][1], case["k"].shape[0] - 2  # last slot of the dummy page
+    for i in (1, 2, 3, 5, 6, 7):
+        case["rows"][i] = dummy_row
+    case["table"][dummy_row].fill_(dummy_slot)
+    out, _ = run_decode(ops, dev, case, max_bs=8)
+    torch.testing.assert_close(out.double(), oracle(case), **TOL)
+
+
+def test_decode_bench_shape_statistics(ops, dev):
+    """BASELINE config 2/3 shape family at reduced batch: 32 requests, lengths 100..2048, GQA 5."""
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(100, 2049, (32,), generator=g).tolist()
+    case = make_case(g, len(lens), 40, 8, lens, 16)
+    out, _ = run_decode(ops, dev, case)
+    torch.testing.assert_close(out.double(), oracle(case), **TOL)
+
+
+def test_decode_fp16(ops, dev):
+    g = torch.Generator().manual_seed(21)
+    lens = [77, 300, 1, 1500]
+    case = make_case(g, len(lens), 16, 8, lens, 1, dtype=torch.float16)
+    out, _ = run_decode(ops, dev, case)
+    torch.testing.assert_close(out.double(), oracle(case), atol=1e-3, rtol=2 ** -9)
+
+
+def test_decode_softmax_extremes(ops, dev):
+    """One key dominates (forces the running-max rescale path) and tokens identical (uniform P)."""
+    g = torch.Generator().manual_seed(33)
+    lens = [700, 700]
+    case = make_case(g, 2, 40, 8, lens, 1)
+    D = 128
+    q = case["qkv"][:, : 40 * D].reshape(2, 40, D)
+    # request 0: spike key at position 650 aligned with head 0's query
+    slot = int(case["table"][case["rows"][0], 650])
+    case["k"][slot, 0] = (q[0, 0].float() * 4).to(torch.bfloat16)
+    # request 1: all keys identical => uniform attention => output = mean(V)
+    slots1 = case["table"][case["rows"][1], :700].long()
+    case["k"][slots1] = case["k"][slots1[0]].clone()
+    out, _ = run_decode(ops, dev, case)
+    ref = oracle(case)
+    torch.testing.assert_close(out.double(), ref, **TOL)
+    mean_v = case["v"][slots1].double().mean(0).repeat_interleave(5, dim=0)
+    torch.testing.assert_close(out[1].double(), mean_v, atol=1e-2, rtol=1e-2)
+
+
+def test_decode_graph_replay(ops, dev):
+    """Capture once with the static-buffer contract (P/attention/fa.py:107-136), replay with
+    different lengths / rows copied into the static buffers."""
+    g = torch.Generator().manual_seed(77)
+    D, hq, hkv, max_bs, capacity = 128, 40, 8, 8, 1024
+    lens_a = [1] * 8
+    case = make_case(g, 8, hq, hkv, [900, 40, 1, 333, 2000, 64, 65, 512], 1)
+    kd, vd, td = case["k"].to(dev), case["v"].to(dev), case["table"].to(dev)
+    seq = torch.tensor(lens_a, dtype=torch.int32, device=dev)
+    rows = torch.tensor(case["rows"], dtype=torch.int32, device=dev)
+    qkv = torch.zeros_like(case["qkv"]).to(dev)
+    q = qkv[:, : hq * D].view(8, hq, D)
+    out = torch.empty((8, hq, D), dtype=torch.bfloat16, device=dev)
+    plan = torch.zeros(ops.attn_decode_plan_words(max_bs, capacity), dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.attn_decode_workspace_bytes(capacity, hq, D), dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.attn_decode_plan(plan, seq, 8, max_bs, capacity, hkv)
+        ops.attn_decode(out, q, kd, vd, td, rows, seq, plan, ws, 8, max_bs, capacity, D ** -0.5)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            ops.attn_decode_plan(plan, seq, 8, max_bs, capacity, hkv)
+            ops.attn_decode(out, q, kd, vd, td, rows, seq, plan, ws, 8, max_bs, capacity, D ** -0.5)
+        # replay with the real batch
+        seq.copy_(torch.tensor(case["lens"], dtype=torch.int32))
+        qkv.copy_(case["qkv"])
+        graph.replay()
+        torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().double(), oracle(case), **TOL)

@@ -1,0 +1,135 @@
+"""Per-kernel micro-benchmarks on one MI355X: GB/s against algorithmic bytes.
+
+    python tools/microbench.py [--out gpurun_out/microbench.json]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import random
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from mini_sglang_amd import ops  # noqa: E402
+
+
+def time_us(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
+def bench_lens(n=256, seed=0):
+    """Context lengths of BASELINE config 2/3 mid-run: input 100..1024 plus a uniform share of the output."""
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        i, o = rnd.randint(100, 1024), rnd.randint(100, 1024)
+        out.append(i + rnd.randint(0, o - 1))
+    return out
+
+
+def decode_case(B, hq, hkv, lens, page_size, dev, dtype=torch.bfloat16, D=128):
+    max_seq = (max(lens) + 31) // 32 * 32
+    pages_per_req = (max_seq + page_size - 1) // page_size
+    n_pages = B * pages_per_req + 1
+    slots = n_pages * page_size
+    k = torch.randn((slots, hkv, D), device=dev, dtype=dtype)
+    v = torch.randn((slots, hkv, D), device=dev, dtype=dtype)
+    perm = torch.randperm(n_pages - 1)
+    table = torch.zeros((B, max_seq), dtype=torch.int32)
+    p = 0
+    for b in range(B):
+        need = (lens[b] + page_size - 1) // page_size
+        pg = perm[p:p + need].to(torch.int32) * page_size
+        p += need
+        tok = (pg.unsqueeze(1) + torch.arange(page_size, dtype=torch.int32)).flatten()
+        table[b, : min(need * page_size, max_seq)] = tok[:max_seq]
+    q = torch.randn((B, hq, D), device=dev, dtype=dtype)
+    return k, v, table.to(dev), q
+
+
+def run(args):
+    dev = torch.device("cuda:0")
+    res = {"device": torch.cuda.get_device_name(0), "cus": ops.lib().msgl_device_cu_count()}
+    it = 2  # bytes per element
+    # ---- decode attention, Qwen3-14B TP1 shape, B=256
+    for name, B, hq, hkv, page in [("decode_14b_b256_p256", 256, 40, 8, 256), ("decode_14b_b256_p1", 256, 40, 8, 1),
+                                   ("decode_0.6b_b256", 256, 16, 8, 256), ("decode_32b_tp4_b256", 256, 16, 2, 256),
+                                   ("decode_70b_tp8_b256", 256, 8, 1, 256), ("decode_14b_b1", 1, 40, 8, 256),
+                                   ("decode_14b_b16", 16, 40, 8, 256)]:
+        lens = bench_lens(B)
+        k, v, table, q = decode_case(B, hq, hkv, lens, page, dev)
+        D = 128
+        cap = max(4096, 2 * B)
+        plan = torch.zeros(ops.attn_decode_plan_words(B, cap), dtype=torch.int32, device=dev)
+        ws = torch.empty(ops.attn_decode_workspace_bytes(cap, hq, D), dtype=torch.uint8, device=dev)
+        seq = torch.tensor(lens, dtype=torch.int32, device=dev)
+        out = torch.empty_like(q)
+        ops.attn_decode_plan(plan, seq, B, B, cap, hkv)
+        f = lambda: ops.attn_decode(out, q, k, v, table, None, seq, plan, ws, B, B, cap, D ** -0.5)
+        us = time_us(f)
+        S = sum(lens)
+        bytes_ = S * 2 * hkv * D * it + 2 * B * hq * D * it + S * 4 + 2 * B * 4
+        pl = plan[:2].tolist()
+        res[name] = dict(us=us, GBps=bytes_ / us / 1e3, bytes=bytes_, sum_len=S, n_items=pl[0], chunk=pl[1])
+        print(name, res[name], flush=True)
+        del k, v, table, q, ws
+    # ---- row ops at decode (T=256) and prefill (T=8192) sizes, hidden 5120
+    for T in (256, 8192):
+        H = 5120
+        x = torch.randn((T, H), device=dev, dtype=torch.bfloat16)
+        r = torch.randn((T, H), device=dev, dtype=torch.bfloat16)
+        w = torch.ones(H, device=dev, dtype=torch.bfloat16)
+        us = time_us(lambda: ops.fused_add_rmsnorm(x, r, w, 1e-6))
+        res[f"fused_add_rmsnorm_T{T}"] = dict(us=us, GBps=(4 * T * H * it + H * it) / us / 1e3)
+        us = time_us(lambda: ops.rmsnorm(x, w, 1e-6, out=r))
+        res[f"rmsnorm_T{T}"] = dict(us=us, GBps=(2 * T * H * it + H * it) / us / 1e3)
+        I = 17408
+        gu = torch.randn((T, 2 * I), device=dev, dtype=torch.bfloat16)
+        o = torch.empty((T, I), device=dev, dtype=torch.bfloat16)
+        us = time_us(lambda: ops.silu_and_mul(gu, out=o))
+        res[f"silu_and_mul_T{T}"] = dict(us=us, GBps=(3 * T * I * it) / us / 1e3)
+        hq, hk, D = 40, 8, 128
+        qkv = torch.randn((T, (hq + 2 * hk) * D), device=dev, dtype=torch.bfloat16)
+        q_, k_, v_ = qkv.split([hq * D, hk * D, hk * D], dim=-1)
+        cache = torch.randn((40960, D), device=dev, dtype=torch.float32)
+        pos = torch.randint(0, 4096, (T,), device=dev, dtype=torch.int32)
+        us = time_us(lambda: ops.rope_neox_inplace(pos, q_, k_, D, cache))
+        res[f"rope_T{T}"] = dict(us=us, GBps=(2 * T * (hq + hk) * D * it + T * D * 4) / us / 1e3)
+        kc = torch.zeros((300000, hk * D), device=dev, dtype=torch.bfloat16)
+        vc = torch.zeros_like(kc)
+        loc = torch.randperm(300000, device=dev)[:T].to(torch.int32)
+        us = time_us(lambda: ops.store_kv(kc, vc, loc, k_, v_))
+        res[f"store_kv_T{T}"] = dict(us=us, GBps=(4 * T * hk * D * it + T * 4) / us / 1e3)
+        qw = torch.ones(D, device=dev, dtype=torch.bfloat16)
+        us = time_us(lambda: ops.qk_norm_rope_store(q_, k_, v_, qw, qw, 1e-6, pos, cache, kc, vc, loc, D))
+        res[f"qk_norm_rope_store_T{T}"] = dict(
+            us=us, GBps=(2 * T * (hq + hk) * D * it + 3 * T * hk * D * it + T * D * 4) / us / 1e3)
+        emb = torch.randn((151936, H), device=dev, dtype=torch.bfloat16)
+        ids = torch.randint(0, 151936, (T,), device=dev, dtype=torch.int32)
+        us = time_us(lambda: ops.embedding_gather(emb, ids))
+        res[f"embedding_gather_T{T}"] = dict(us=us, GBps=(2 * T * H * it) / us / 1e3)
+        for kname in list(res):
+            if kname.endswith(f"_T{T}"):
+                print(kname, res[kname], flush=True)
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.out).write_text(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/microbench.json")
+    run(ap.parse_args())
