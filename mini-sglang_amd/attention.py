@@ -1,0 +1,159 @@
+"""HipAttnBackend: the MI355X attention backend behind the reference's plugin API.
+
+Implements the five abstract methods of BaseAttnBackend (P/attention/base.py:18-34) and the
+metadata contract (`get_last_indices`, P/attention/base.py:12-15, fa.py:32-33) with the gfx950
+kernels.  Differences from the reference backends that matter for speed, none for results:
+
+* the page table is read IN PLACE: the kernels walk `ctx.page_table[req.table_idx, :len]`
+  (token slots, page-size agnostic) directly, so `prepare_metadata` builds no per-step
+  `[B, max_k / page]` table (cf. fa.py:92-97: B slice views + a stack + a div per step) and
+  graph replay copies two `[B]` int vectors instead of a `[B, max_seq/page]` table;
+* all per-batch integers travel in ONE pinned host buffer / ONE async H2D copy;
+* decode work is split by a device-side plan (no host sync, fixed grids => graph-safe).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, List, Optional
+
+import torch
+
+from . import _lib, ops
+from . import core as _core
+
+
+@dataclass
+class HipAttnMetadata:
+    cu_seqlens_q: torch.Tensor  # [B+1] int32, device
+    seq_lens: torch.Tensor      # [B]   int32, device (= cache_seqlens / device_len)
+    req_rows: torch.Tensor      # [B]   int32, device (= req.table_idx)
+    batch: int
+    max_seqlen_q: int
+    max_seqlen_k: int
+    tile_cu: Optional[torch.Tensor] = None  # [B+1] int32 (prefill only)
+    total_tiles: int = 0
+    plan: Optional[torch.Tensor] = None     # decode work list (device)
+
+    def get_last_indices(self, bs: int) -> torch.Tensor:
+        return self.cu_seqlens_q[1: 1 + bs] - 1
+
+
+class HipAttnBackend:
+    """Paged attention (prefill + decode) over the reference's KV pool and global page table."""
+
+    def __init__(self, config: Any, ctx: Any = None, *, tp_size: int = 1, decode_capacity: int = 0) -> None:
+        ctx = ctx if ctx is not None else _core.get_global_ctx()
+        self.ctx = ctx
+        self.config = config
+        self.kvcache = ctx.kv_cache
+        self.page_size = ctx.page_size
+        self.device = self.kvcache.device
+        self.head_dim = config.head_dim
+        self.scale = config.head_dim ** -0.5
+        self.qo_heads = config.num_qo_heads // tp_size
+        self.kv_heads = max(config.num_kv_heads // tp_size, 1)
+        self.max_bs = int(ctx.page_table.shape[0])
+        self.capacity = decode_capacity or max(4096, 4 * self.max_bs)
+        self._workspace = torch.empty(ops.attn_decode_workspace_bytes(self.capacity, self.qo_heads, self.head_dim),
+                                      dtype=torch.uint8, device=self.device)
+        self._plan_words = ops.attn_decode_plan_words(self.max_bs, self.capacity)
+        # graph state
+        self.capture_bs: List[int] = []
+        self.max_graph_bs = 0
+        self._cap_seq: Optional[torch.Tensor] = None
+        self._cap_rows: Optional[torch.Tensor] = None
+        self._cap_plan: Optional[torch.Tensor] = None
+        self._cap_cu_q: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ forward
+    def _kv_tokens(self, layer_id: int):
+        k = self.kvcache.k_cache(layer_id)
+        v = self.kvcache.v_cache(layer_id)
+        return k.view(-1, k.shape[-2], k.shape[-1]), v.view(-1, v.shape[-2], v.shape[-1])
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, layer_id: int, batch: Any) -> torch.Tensor:
+        """Reference contract (fa.py:48-65): persist k, v at batch.out_loc, then attend."""
+        self.kvcache.store_kv(k, v, batch.out_loc, layer_id)
+        return self.attend(q, layer_id, batch)
+
+    def attend(self, q: torch.Tensor, layer_id: int, batch: Any) -> torch.Tensor:
+        """Attention only (K/V for this batch already in the pool, e.g. via the fused
+        qk-norm + RoPE + store kernel)."""
+        md: HipAttnMetadata = batch.attn_metadata
+        q = q.view(-1, self.qo_heads, self.head_dim)
+        out = torch.empty((q.shape[0], self.qo_heads, self.head_dim), dtype=q.dtype, device=q.device)
+        k_tok, v_tok = self._kv_tokens(layer_id)
+        table = self.ctx.page_table
+        if md.max_seqlen_q == 1:
+            ops.attn_decode(out, q, k_tok, v_tok, table, md.req_rows, md.seq_lens, md.plan, self._workspace,
+                            md.batch, self.max_bs, self.capacity, self.scale)
+        else:
+            ops.attn_prefill(out, q, k_tok, v_tok, table, md.req_rows, md.seq_lens, md.cu_seqlens_q, md.tile_cu,
+                             md.batch, md.total_tiles, self.scale)
+        return out
+
+    # ------------------------------------------------------------------ metadata
+    def prepare_metadata(self, batch: Any) -> None:
+        reqs = batch.padded_reqs
+        bs = len(reqs)
+        seqlens_q = [r.extend_len for r in reqs]
+        seqlens_k = [r.device_len for r in reqs]
+        max_q, max_k = max(seqlens_q), max(seqlens_k)
+        decode = max_q == 1
+        # one pinned buffer: [seq_lens | rows | cu_q | tile_cu]
+        host = torch.empty(4 * bs + 2, dtype=torch.int32, pin_memory=True)
+        host[:bs] = torch.tensor(seqlens_k, dtype=torch.int32)
+        host[bs: 2 * bs] = torch.tensor([r.table_idx for r in reqs], dtype=torch.int32)
+        cu_q = host[2 * bs: 3 * bs + 1]
+        cu_q[0] = 0
+        torch.cumsum(torch.tensor(seqlens_q, dtype=torch.int32), 0, out=cu_q[1:])
+        tile_cu = host[3 * bs + 1: 4 * bs + 2]
+        total_tiles = 0
+        if not decode:
+            tiles = torch.tensor([(n + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE for n in seqlens_q],
+                                 dtype=torch.int32)
+            tile_cu[0] = 0
+            torch.cumsum(tiles, 0, out=tile_cu[1:])
+            total_tiles = int(tile_cu[-1])
+        dev = host.to(self.device, non_blocking=True)
+        md = HipAttnMetadata(
+            cu_seqlens_q=dev[2 * bs: 3 * bs + 1], seq_lens=dev[:bs], req_rows=dev[bs: 2 * bs], batch=bs,
+            max_seqlen_q=max_q, max_seqlen_k=max_k, tile_cu=None if decode else dev[3 * bs + 1:],
+            total_tiles=total_tiles,
+        )
+        if decode and not (self._cap_plan is not None and bs in self.capture_bs):
+            # eager decode: plan now (device side, no sync); graph batches are planned in prepare_for_replay
+            md.plan = torch.empty(self._plan_words, dtype=torch.int32, device=self.device)
+            ops.attn_decode_plan(md.plan, md.seq_lens, bs, self.max_bs, self.capacity, self.kv_heads)
+        batch.attn_metadata = md
+
+    # ------------------------------------------------------------------ graph hooks
+    def init_capture_graph(self, max_seq_len: int, bs_list: List[int]) -> None:
+        assert self._cap_plan is None, "Capture already initialized."
+        max_bs = max(bs_list)
+        assert max_bs <= self.max_bs
+        self.max_graph_bs = max_bs
+        self.capture_bs = sorted(bs_list)
+        self._cap_seq = torch.ones(max_bs, dtype=torch.int32, device=self.device)
+        self._cap_rows = torch.zeros(max_bs, dtype=torch.int32, device=self.device)
+        self._cap_cu_q = torch.arange(0, max_bs + 1, dtype=torch.int32, device=self.device)
+        self._cap_plan = torch.zeros(self._plan_words, dtype=torch.int32, device=self.device)
+
+    def prepare_for_capture(self, batch: Any) -> None:
+        bs = batch.size
+        assert bs in self.capture_bs and self._cap_plan is not None
+        # dummy requests: length 1, all rows = the dummy request's table row
+        self._cap_rows[:bs].fill_(batch.reqs[0].table_idx)
+        self._cap_seq[:bs].fill_(1)
+        ops.attn_decode_plan(self._cap_plan, self._cap_seq, bs, self.max_bs, self.capacity, self.kv_heads)
+        batch.attn_metadata = HipAttnMetadata(
+            cu_seqlens_q=self._cap_cu_q[: bs + 1], seq_lens=self._cap_seq[:bs], req_rows=self._cap_rows[:bs],
+            batch=bs, max_seqlen_q=1, max_seqlen_k=int(self.ctx.page_table.shape[1]), plan=self._cap_plan,
+        )
+
+    def prepare_for_replay(self, batch: Any) -> None:
+        md, bs = batch.attn_metadata, batch.padded_size
+        assert isinstance(md, HipAttnMetadata) and bs in self.capture_bs and self._cap_plan is not None
+        self._cap_seq[:bs].copy_(md.seq_lens)
+        self._cap_rows[:bs].copy_(md.req_rows)
+        ops.attn_decode_plan(self._cap_plan, self._cap_seq, bs, self.max_bs, self.capacity, self.kv_heads)
