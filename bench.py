@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s of the MI355X paged-attention serving core.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W        (N > 1: TP = N over RCCL)
+
+Workload (BASELINE.json: metric quoted on Qwen3-14B TP=1; fits one GPU => configs[2]'s model on
+configs[1]'s request shape): Qwen3-14B bf16, 256 sequences, context lengths drawn from the
+token-weighted context distribution of the reference's offline benchmark
+(benchmark/offline/bench.py:11-31: in/out 100..1024, mean context per decoded token 902.8),
+page_size 256, temperature 0.6, seeded N(0, 0.02^2) weights (no checkpoints offline), synthetic
+token ids.  The prompts are first prefetched with the real chunked-prefill path
+(max_extend_tokens 16384) -- that gives p50 TTFT -- then ONE STEP = one decode forward of the
+whole batch: metadata prep, hipGraph replay of the 40-layer model (hand-written gfx950 kernels +
+hipBLASLt GEMMs), sampling, token feedback.  Nothing is skipped inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (paged decode attention:
+~58% of the step's algorithmic bytes), timed live with HIP events on the launch stream;
+`cpu_baseline` is the oracle's torch-eager forward on this node's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+METRIC = "decode tokens/s/GPU + p50 TTFT, Qwen3-14B TP=1 and Qwen3-32B TP=4"
+
+
+def bench_contexts(num_seqs: int, seed: int = 0):
+    """(request, decode step) pairs drawn uniformly from all decoded tokens of the reference's
+    offline benchmark => context lengths with its token-weighted mean (902.8 at 256 seqs)."""
+    rnd = random.Random(seed)
+    ins = [rnd.randint(100, 1024) for _ in range(256)]
+    outs = [rnd.randint(100, 1024) for _ in range(256)]
+    pick = random.Random(seed + 1)
+    reqs = pick.choices(range(256), weights=outs, k=num_seqs)
+    return [ins[r] + pick.randint(0, outs[r] - 1) for r in reqs]
+
+
+def cpu_baseline(cfg, contexts, seconds_budget: float = 25.0):
+    """Oracle (oracle/ref_model.py) timed on the host cores: `layers_s` decoder layers + LM head of
+    the SAME model dims at a reduced batch, extrapolated to the full depth.  A reported baseline,
+    not a target."""
+    from oracle import ref_model, ref_ops
+
+    # a many-socket host thrashes when torch spreads an M=8 GEMV over every hardware thread
+    # (measured: 256 threads => 470 s/step); cap, and report the threads actually used
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MSGL_CPU_BASELINE_THREADS", "32")))
+    torch.set_num_threads(cores)
+    B, L = 8, 2
+    lens = contexts[:B]
+    D = cfg.head_dim
+    g = torch.Generator().manual_seed(0)
+    w = ref_model.random_weights(
+        type("C", (), dict(cfg.__dict__, vocab_size=10000, tie_word_embeddings=True))(), torch.float32, num_layers=L)
+    lm_head = torch.randn((cfg.vocab_size, cfg.hidden_size), generator=g) * 0.02
+    w.lm_head = lm_head
+    max_len = max(lens) + 8
+    slots = B * max_len
+    table = torch.arange(slots, dtype=torch.int32).view(B, max_len)
+    kp = [torch.randn((slots, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
+    vp = [torch.randn((slots, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
+    ids = torch.randint(0, 10000, (B,), generator=g)
+
+    def step(cur):
+        pos = torch.tensor([n - 1 for n in cur], dtype=torch.int32)
+        loc = table[torch.arange(B), pos.long()]
+        return ref_model.forward(cfg, w, ids, pos, loc, kp, vp, table, list(range(B)), cur, [1] * B, False)
+
+    def layers_only(cur):
+        pos = torch.tensor([n - 1 for n in cur], dtype=torch.int32)
+        loc = table[torch.arange(B), pos.long()]
+        w2 = ref_model.CpuWeights(w.embed, w.layers, w.final_norm, w.lm_head[:8], w.cos_sin)
+        return ref_model.forward(cfg, w2, ids, pos, loc, kp, vp, table, list(range(B)), cur, [1] * B, False)
+
+    step(lens)  # warm-up
+    t_full, t_lay = [], []
+    t_start = time.perf_counter()
+    for i in range(5):
+        cur = [n + i + 1 for n in lens]
+        t0 = time.perf_counter(); step(cur); t1 = time.perf_counter()
+        layers_only(cur); t2 = time.perf_counter()
+        t_full.append(t1 - t0); t_lay.append(t2 - t1)
+        if time.perf_counter() - t_start > seconds_budget:
+            break
+    t_full.sort(); t_lay.sort()
+    full, lay = t_full[len(t_full) // 2], t_lay[len(t_lay) // 2]
+    per_layer = lay / L
+    head = max(full - lay, 0.0)
+    est_step = per_layer * cfg.num_layers + head
+    return dict(value=B / est_step, unit="tokens/s", cores=cores, kind="port",
+                sample=f"torch-eager oracle, {cfg.name} dims, batch {B} (contexts {lens}), {L} of "
+                       f"{cfg.num_layers} layers + LM head timed ({len(t_full)} steps, median), extrapolated "
+                       f"to {cfg.num_layers} layers: {est_step * 1e3:.0f} ms/step")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="qwen3-14b")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--page-size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="fill the KV pool with random data instead")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.model import PRESETS
+    from mini_sglang_amd.offline import OfflineRunner
+
+    import torch.distributed as dist
+
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        from mini_sglang_amd.kernel import init_pynccl
+
+        comm = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=0)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+
+    mcfg = PRESETS[args.model]
+    B = args.batch
+    contexts = bench_contexts(B)
+    use_graph = os.environ.get("MSGL_BENCH_NO_GRAPH", "0") != "1"
+    max_seq = 4096  # max_seq_len_override of the reference bench
+    ecfg = EngineConfig(model=mcfg, dtype=torch.bfloat16, tp_rank=rank, tp_size=world, max_running_req=B,
+                        cuda_graph_bs=[B] if use_graph else [], page_size=args.page_size,
+                        max_seq_len_override=max_seq, comm=comm, memory_ratio=0.9)
+    try:
+        engine = Engine(ecfg, device)
+    except Exception as e:  # graph capture with a collective inside may be refused: run eager
+        if not use_graph:
+            raise
+        print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+        ecfg.cuda_graph_bs = []
+        use_graph = False
+        engine = Engine(ecfg, device)
+    runner = OfflineRunner(engine, max_extend_tokens=16384, seed=0)
+
+    rnd = random.Random(1234)
+    prompts = [[rnd.randint(0, 10000) for _ in range(n)] for n in contexts]
+    total_steps = args.steps + args.warmup
+    sp = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=total_steps + 8) for _ in range(B)]
+    states = [runner.add_request(p, s) for p, s in zip(prompts, sp)]
+
+    # ---------------- prefill (untimed for `value`; yields TTFT) ----------------
+    ttft_p50 = None
+    barrier()
+    if args.no_prefill:
+        engine.kv_cache._kv_buffer.normal_(0.0, 1.0)
+        for st in states:
+            st.req.cached_len, st.req.device_len = st.prompt_len - 1, st.prompt_len
+        runner._allocate_paged([type("R", (), dict(table_idx=s.req.table_idx, cached_len=0,
+                                                   device_len=s.prompt_len))() for s in states])
+    else:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        evs = []
+        for out, finals in runner.prefill(states):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            evs.append((ev, len(finals)))
+        torch.cuda.synchronize(device)
+        ttft = sorted(t for ev, n in evs for t in [ev0.elapsed_time(ev)] * n)
+        ttft_p50 = ttft[int(len(ttft) * 0.5)]  # percentile rule of P/benchmark/client.py:324-348
+    running = list(states)
+
+    # ---------------- decode: W warm-up + K timed steps ----------------
+    for _ in range(args.warmup):
+        runner.decode_step(running)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.decode_step(running)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    ms_per_step = elapsed * 1e3 / args.steps
+    tokens_per_s = B * args.steps / elapsed
+
+    # ---------------- roofline of the dominant kernel (paged decode attention) ----------------
+    lens_now = [s.req.device_len for s in running]  # contexts of the next step
+    be = engine.attn_backend
+    it = 2
+    hq, hkv, D = be.qo_heads, be.kv_heads, mcfg.head_dim
+    seq = torch.tensor(lens_now, dtype=torch.int32, device=device)
+    rows = torch.tensor([s.req.table_idx for s in running], dtype=torch.int32, device=device)
+    plan = torch.empty(be._plan_words, dtype=torch.int32, device=device)
+    ops.attn_decode_plan(plan, seq, B, be.max_bs, be.capacity, hkv)
+    q = torch.randn((B, hq, D), device=device, dtype=torch.bfloat16)
+    o = torch.empty_like(q)
+    k_tok, v_tok = be._kv_tokens(0)
+    launch = lambda: ops.attn_decode(o, q, k_tok, v_tok, engine.page_table, rows, seq, plan, be._workspace, B,  # noqa: E731
+                                     be.max_bs, be.capacity, be.scale)
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 30
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    e1.synchronize()
+    attn_us = e0.elapsed_time(e1) * 1e3 / reps  # partial + merge kernels of one layer
+    S = sum(lens_now)
+    attn_bytes = S * 2 * hkv * D * it + 2 * B * hq * D * it + S * 4 + 2 * B * 4
+    achieved = attn_bytes / attn_us / 1e3
+    # whole-step algorithmic bytes per rank: streamed weights + KV read/write + logits
+    kv_tok = 2 * mcfg.num_layers * hkv * D * it
+    step_bytes = engine.model.streamed_bytes_per_step() + (S + B) * kv_tok + B * mcfg.vocab_size * it
+    step_gbps = step_bytes / (ms_per_step * 1e-3) / 1e9
+
+    result = {
+        "metric": METRIC, "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {
+            "workload": f"{mcfg.name} bf16 decode step, {B} seqs, contexts from the offline-bench token-weighted "
+                        f"distribution (mean {S / B:.0f}), page_size {args.page_size}, temperature 0.6, hipGraph "
+                        f"{'on' if use_graph else 'off'}",
+            "batch": B, "parallelism": f"tp{world}", "mean_context": S / B,
+        },
+        "ttft_p50_ms": ttft_p50,
+        "roofline": {
+            "bound": "hbm", "kernel": "attn_decode_kernel (+merge), one layer", "achieved": achieved,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "us_per_launch": attn_us, "algorithmic_bytes": attn_bytes,
+        },
+        "step_roofline": {
+            "bound": "hbm", "bytes_per_step_per_rank": step_bytes, "achieved": step_gbps, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS,
+            "roofline_tokens_per_s": B * HBM_PEAK_GBPS * 1e9 / step_bytes * (1 if world == 1 else 1),
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        engine.shutdown()
+        try:
+            result["cpu_baseline"] = cpu_baseline(mcfg, contexts)
+        except Exception as e:  # never lose the GPU numbers to a host-side problem
+            result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        engine.shutdown()
+        if comm is not None:
+            comm.destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# Load order matters: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Importing torch
+# first makes our shared objects bind to that already-loaded runtime (same SONAME) instead of
+# pulling a second copy from /opt/rocm, which would see no device.
+import torch  # noqa: F401
+
 _PKG = Path(__file__).resolve().parent
 LIB_DIR = _PKG / "lib"
 HIP_SO = LIB_DIR / "libmsgl_hip.so"

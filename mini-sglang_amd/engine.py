@@ -1,0 +1,241 @@
+"""Per-rank engine: model + KV pool + page table + attention backend + sampler + hipGraph runner.
+
+Host-side mirror of the reference's L4 (P/engine/engine.py:29-211, graph.py:21-171,
+sample.py:24-75) restricted to what drives the hot path.  The reference's own Engine runs
+unchanged on the plugin when `minisgl` is installed; this one exists for the
+GPU box, where only this repository is present.
+"""
+from __future__ import annotations
+
+import gc
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, NamedTuple, Optional
+
+import torch
+
+from . import flashinfer_compat as fi
+from . import ops
+from .attention import HipAttnBackend
+from .core import Batch, Context, Req, SamplingParams, set_global_ctx
+from .kvcache import create_kvcache_pool, div_even
+from .model import Communicator, DenseDecoder, ModelConfig
+
+
+# ------------------------------------------------------------------------------ sampler
+@dataclass
+class BatchSamplingArgs:
+    temperatures: Optional[torch.Tensor]
+    top_k: Optional[torch.Tensor] = None
+    top_p: Optional[torch.Tensor] = None
+
+
+def _device_tensor(data: List, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    return torch.tensor(data, dtype=dtype, pin_memory=True).to(device, non_blocking=True)
+
+
+@dataclass
+class Sampler:
+    """P/engine/sample.py:49-75 with the same clamps (MIN_T = MIN_P = 1e-6)."""
+    device: torch.device
+    vocab_size: int
+
+    def prepare(self, batch: Batch) -> BatchSamplingArgs:
+        params = [r.sampling_params for r in batch.reqs]
+        if all(p.is_greedy for p in params):
+            return BatchSamplingArgs(temperatures=None)
+        MIN_P = MIN_T = 1e-6
+        ts = [max(0.0 if p.is_greedy else p.temperature, MIN_T) for p in params]
+        top_ks = [p.top_k if p.top_k >= 1 else self.vocab_size for p in params]
+        top_ps = [min(max(p.top_p, MIN_P), 1.0) for p in params]
+        temperatures = _device_tensor(ts, torch.float32, self.device)
+        top_k = top_p = None
+        if any(k != self.vocab_size for k in top_ks):
+            top_k = _device_tensor(top_ks, torch.int32, self.device)
+        if any(p < 1.0 for p in top_ps):
+            top_p = _device_tensor(top_ps, torch.float32, self.device)
+        return BatchSamplingArgs(temperatures, top_k=top_k, top_p=top_p)
+
+    def sample(self, logits: torch.Tensor, args: BatchSamplingArgs) -> torch.Tensor:
+        if args.temperatures is None:  # greedy: first index of the row max
+            return ops.argmax_rows(logits)
+        probs = fi.sampling.softmax(logits, args.temperatures)
+        if args.top_k is None and args.top_p is None:
+            return fi.sampling.sampling_from_probs(probs)
+        if args.top_p is None:
+            return fi.sampling.top_k_sampling_from_probs(probs, args.top_k)
+        if args.top_k is None:
+            return fi.sampling.top_p_sampling_from_probs(probs, args.top_p)
+        return fi.sampling.top_k_top_p_sampling_from_probs(probs, args.top_k, args.top_p)
+
+
+# ------------------------------------------------------------------------------ config
+@dataclass
+class EngineConfig:
+    """Fields of P/engine/config.py:16-55 that reach the hot path."""
+    model: ModelConfig
+    dtype: torch.dtype = torch.bfloat16
+    tp_rank: int = 0
+    tp_size: int = 1
+    max_running_req: int = 256
+    cuda_graph_bs: Optional[List[int]] = None
+    cuda_graph_max_bs: Optional[int] = None
+    page_size: int = 1
+    memory_ratio: float = 0.9
+    max_seq_len_override: Optional[int] = None
+    num_page_override: Optional[int] = None
+    fused_qkv_path: bool = True
+    comm: Any = None  # RcclCommunicator (tp_size > 1)
+    seed: int = 42
+
+    @property
+    def max_seq_len(self) -> int:
+        return self.max_seq_len_override or self.model.max_position
+
+
+class ForwardOutput(NamedTuple):
+    next_tokens_gpu: torch.Tensor
+    next_tokens_cpu: torch.Tensor
+    copy_done_event: torch.cuda.Event
+
+
+def _align_up_32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+def determine_num_pages(free_before: int, free_after: int, cfg: EngineConfig) -> int:
+    """P/engine/engine.py:148-168: (memory_ratio * free_before - model_bytes) // bytes_per_page."""
+    m = cfg.model
+    cache_per_page = (2 * m.head_dim * div_even(m.num_kv_heads, cfg.tp_size, allow_replicate=True) * cfg.page_size
+                      * torch.empty((), dtype=cfg.dtype).element_size() * m.num_layers)
+    if cfg.num_page_override is not None:
+        return cfg.num_page_override
+    model_memory = free_before - free_after
+    available = int(cfg.memory_ratio * free_before) - model_memory
+    num_pages = available // cache_per_page
+    assert num_pages > 1, "Not enough memory for KV cache"
+    return num_pages
+
+
+def determine_graph_bs(cuda_graph_bs: Optional[List[int]], cuda_graph_max_bs: Optional[int],
+                       free_memory: int) -> List[int]:
+    """P/engine/graph.py:49-67."""
+    if cuda_graph_bs is not None:
+        return cuda_graph_bs
+    if cuda_graph_max_bs is None:
+        cuda_graph_max_bs = 256 if free_memory / (1 << 30) > 80 else 160
+    if cuda_graph_max_bs < 1:
+        return []
+    return [b for b in [1, 2, 4] if b <= cuda_graph_max_bs] + list(range(8, cuda_graph_max_bs + 1, 8))
+
+
+# ------------------------------------------------------------------------------ graph runner
+class GraphRunner:
+    """hipGraph capture/replay of the decode forward, P/engine/graph.py:78-171."""
+
+    def __init__(self, engine: "Engine", bs_list: List[int]) -> None:
+        self.engine = engine
+        self.graph_bs_list = sorted(bs_list)
+        self.max_graph_bs = max(bs_list) if bs_list else 0
+        self.graph_map: Dict[int, torch.cuda.CUDAGraph] = {}
+        if not bs_list:
+            return
+        dev, V = engine.device, engine.cfg.model.vocab_size
+        self.input_ids = torch.zeros(self.max_graph_bs, dtype=torch.int32, device=dev)
+        self.out_loc = torch.zeros(self.max_graph_bs, dtype=torch.int32, device=dev)
+        self.positions = torch.zeros(self.max_graph_bs, dtype=torch.int32, device=dev)
+        self.logits = torch.empty((self.max_graph_bs, V), dtype=torch.float32, device=dev)  # graph.py:33
+        backend = engine.attn_backend
+        backend.init_capture_graph(max_seq_len=engine.aligned_max_seq_len, bs_list=self.graph_bs_list)
+        torch.cuda.synchronize(dev)
+        pool = None
+        for bs in sorted(self.graph_bs_list, reverse=True):
+            graph = torch.cuda.CUDAGraph()
+            batch = Batch(reqs=[engine.dummy_req] * bs, phase="decode")
+            batch.padded_reqs = batch.reqs
+            backend.prepare_for_capture(batch)
+            batch.input_ids, batch.out_loc, batch.positions = self.input_ids[:bs], self.out_loc[:bs], self.positions[:bs]
+            with engine.ctx.forward_batch(batch):
+                self.logits[:bs] = engine.model.forward(engine.ctx, batch)
+                with torch.cuda.graph(graph, pool=pool, stream=engine.stream):
+                    self.logits[:bs] = engine.model.forward(engine.ctx, batch)
+            if pool is None:
+                pool = graph.pool()
+            self.graph_map[bs] = graph
+
+    def can_use_cuda_graph(self, batch: Batch) -> bool:
+        return batch.is_decode and batch.size <= self.max_graph_bs
+
+    def pad_batch(self, batch: Batch) -> None:
+        padded = (next(bs for bs in self.graph_bs_list if bs >= batch.size)
+                  if self.can_use_cuda_graph(batch) else batch.size)
+        batch.padded_reqs = batch.reqs + [self.engine.dummy_req] * (padded - batch.size)
+
+    def replay(self, batch: Batch) -> torch.Tensor:
+        n = batch.padded_size
+        self.input_ids[:n] = batch.input_ids
+        self.out_loc[:n] = batch.out_loc
+        self.positions[:n] = batch.positions
+        self.engine.attn_backend.prepare_for_replay(batch)
+        self.graph_map[n].replay()
+        return self.logits[: batch.size]
+
+    def destroy(self) -> None:
+        self.graph_map = {}
+        gc.collect()
+
+
+# ------------------------------------------------------------------------------ engine
+class Engine:
+    def __init__(self, cfg: EngineConfig, device: Optional[torch.device] = None) -> None:
+        self.cfg = cfg
+        self.device = device or torch.device(f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        torch.manual_seed(cfg.seed)  # every TP rank seeds identically (P/engine/engine.py:37)
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        self.dtype = cfg.dtype
+        self.ctx = Context(cfg.page_size)
+        set_global_ctx(self.ctx, force=True)
+
+        torch.cuda.synchronize(self.device)
+        free_before = torch.cuda.mem_get_info(self.device)[0]
+        comm = Communicator(cfg.comm, cfg.tp_size)
+        self.model = DenseDecoder(cfg.model, dtype=cfg.dtype, device=self.device, tp_rank=cfg.tp_rank,
+                                  tp_size=cfg.tp_size, seed=cfg.seed, comm=comm, fused=cfg.fused_qkv_path)
+        torch.cuda.synchronize(self.device)
+        free_after = torch.cuda.mem_get_info(self.device)[0]
+
+        self.num_pages = determine_num_pages(free_before, free_after, cfg)
+        num_tokens = self.num_pages * cfg.page_size
+        self.ctx.kv_cache = self.kv_cache = create_kvcache_pool(
+            cfg.model, self.num_pages + 1, cfg.page_size, cfg.dtype, self.device, tp_size=cfg.tp_size)  # +1 dummy
+        self.max_seq_len = min(cfg.max_seq_len, num_tokens)
+        self.aligned_max_seq_len = _align_up_32(self.max_seq_len)
+        self.ctx.page_table = self.page_table = torch.zeros(
+            (cfg.max_running_req + 1, self.aligned_max_seq_len), dtype=torch.int32, device=self.device)
+        self.ctx.attn_backend = self.attn_backend = HipAttnBackend(cfg.model, self.ctx, tp_size=cfg.tp_size)
+        self.sampler = Sampler(self.device, cfg.model.vocab_size)
+        self.dummy_req = Req(input_ids=torch.tensor([0], dtype=torch.int32), table_idx=cfg.max_running_req,
+                             cached_len=0, output_len=1, uid=-1)
+        self.page_table[self.dummy_req.table_idx].fill_(num_tokens)  # the dummy page
+        bs_list = determine_graph_bs(cfg.cuda_graph_bs, cfg.cuda_graph_max_bs, free_before)
+        bs_list = [b for b in bs_list if b <= cfg.max_running_req]
+        self.graph_runner = GraphRunner(self, bs_list)
+
+    def forward_batch(self, batch: Batch, args: BatchSamplingArgs) -> ForwardOutput:
+        """P/engine/engine.py:191-206."""
+        with self.ctx.forward_batch(batch):
+            if self.graph_runner.can_use_cuda_graph(batch):
+                logits = self.graph_runner.replay(batch)
+            else:
+                logits = self.model.forward(self.ctx, batch)
+        for req in batch.reqs:
+            req.complete_one()
+        next_tokens_gpu = self.sampler.sample(logits[: batch.size], args).to(torch.int32)
+        next_tokens_cpu = next_tokens_gpu.to("cpu", non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ForwardOutput(next_tokens_gpu, next_tokens_cpu, ev)
+
+    def shutdown(self) -> None:
+        self.graph_runner.destroy()

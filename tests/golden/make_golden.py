@@ -157,7 +157,7 @@ def gen_fa_metadata():
     torch.save(out, OUT / "fa_metadata.pt")
 
 
-def gen_cache_allocate():
+def gen_cache_allocate(use_product_compare: bool = False):
     """Drive the reference CacheManager + RadixPrefixCache on CPU (the scenario family of
     tests/core/test_cache_allocate.py) and record page tables, free lists and every key
     compare the radix tree performed."""
@@ -176,10 +176,17 @@ def gen_cache_allocate():
             calls.append((x.clone(), y.clone(), r))
         return r
 
-    kradix.fast_compare_key = py_compare
     import minisgl.kernel as mk
 
-    mk.fast_compare_key = py_compare
+    if use_product_compare:  # the drop-in: mini_sglang_amd's C-ABI function behind minisgl.kernel
+        sys.path.insert(0, str(OUT.parent.parent))
+        from mini_sglang_amd import minisgl_plugin
+
+        minisgl_plugin.install()
+        assert mk.fast_compare_key.__module__.startswith("mini_sglang_amd")
+    else:
+        kradix.fast_compare_key = py_compare
+        mk.fast_compare_key = py_compare
 
     out = {}
     for page_size in (1, 4):
@@ -222,6 +229,8 @@ def gen_cache_allocate():
         out[f"page{page_size}"] = dict(num_pages=num_pages, trace=trace)
     out["compare_calls"] = calls
     core._GLOBAL_CTX = None
+    if use_product_compare:
+        return out
     torch.save(out, OUT / "cache_allocate.pt")
 
 
@@ -246,10 +255,10 @@ def gen_indexing_and_store():
 
     # tests/kernel/test_store.py:15-34: strided views of an interleaved cache and of a fused qkv
     H = 128
-    kv_cache = torch.randn((256, 2, H), generator=g).to(torch.float16)
+    kv_cache = torch.randn((96, 2, H), generator=g).to(torch.float16)
     before = kv_cache.clone()
     k_cache, v_cache = kv_cache[:, 0, :], kv_cache[:, 1, :]
-    indices = torch.randperm(256, generator=g)[:33].to(torch.int32)
+    indices = torch.randperm(96, generator=g)[:33].to(torch.int32)
     qkv = torch.randn((33, H * 4), generator=g).to(torch.float16)
     k, v = qkv[:, :H], qkv[:, H: H * 2]
     k_cache[indices.long()] = k  # the reference test's own baseline (index assignment)
@@ -257,8 +266,30 @@ def gen_indexing_and_store():
     torch.save(dict(before=before, indices=indices, qkv=qkv, after=kv_cache.clone()), OUT / "store.pt")
 
 
+def check_plugin() -> None:
+    """The reference's radix cache + CacheManager driven through the plugin's fast_compare_key must
+    reproduce the committed golden trace bit for bit; the registry must know the `hip` backend."""
+    got = gen_cache_allocate(use_product_compare=True)
+    gold = torch.load(OUT / "cache_allocate.pt")
+    for key in ("page1", "page4"):
+        for a, b in zip(got[key]["trace"], gold[key]["trace"]):
+            for f in ("matched", "table_idx"):
+                assert a[f] == b[f], (key, a["step"], f)
+            for f in ("prefill_row", "final_row", "free_slots"):
+                assert torch.equal(a[f], b[f]), (key, a["step"], f)
+            assert a["evictable"] == b["evictable"]
+    from minisgl.attention import SUPPORTED_ATTENTION_BACKENDS, validate_attn_backend
+
+    assert "hip" in SUPPORTED_ATTENTION_BACKENDS.supported_names()
+    validate_attn_backend("hip,hip")
+    print("plugin check ok")
+
+
 if __name__ == "__main__":
     assert REF.exists(), "run this where /root/reference is mounted"
+    if "--check-plugin" in sys.argv:
+        check_plugin()
+        sys.exit(0)
     gen_rope()
     gen_sampler()
     gen_fa_metadata()
