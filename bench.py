@@ -156,7 +156,8 @@ def main() -> None:
     max_seq = 4096  # max_seq_len_override of the reference bench
     ecfg = EngineConfig(model=mcfg, dtype=torch.bfloat16, tp_rank=rank, tp_size=world, max_running_req=B,
                         cuda_graph_bs=[B] if use_graph else [], page_size=args.page_size,
-                        max_seq_len_override=max_seq, comm=comm, memory_ratio=0.9)
+                        max_seq_len_override=max_seq, comm=comm, memory_ratio=0.9,
+                        gemm_tune=os.environ.get("MSGL_GEMM_TUNE", "full"))
     try:
         engine = Engine(ecfg, device)
     except Exception as e:  # graph capture with a collective inside may be refused: run eager
@@ -225,7 +226,7 @@ def main() -> None:
     o = torch.empty_like(q)
     k_tok, v_tok = be._kv_tokens(0)
     launch = lambda: ops.attn_decode(o, q, k_tok, v_tok, engine.page_table, rows, seq, plan, be._workspace, B,  # noqa: E731
-                                     be.max_bs, be.capacity, be.scale)
+                                     be.max_bs, be.capacity, be.scale, slot_run=be.slot_run)
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,6 +266,14 @@ def main() -> None:
             "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS,
             "roofline_tokens_per_s": B * HBM_PEAK_GBPS * 1e9 / step_bytes * (1 if world == 1 else 1),
         },
+    }
+    # library GEMM solution search done at engine start (csrc/gemm.cpp): heuristic pick vs chosen, per launch
+    result["gemm_tune"] = {
+        "mode": ecfg.gemm_tune,
+        "shapes": [dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], heuristic_us=round(r["default_us"], 1),
+                        tuned_us=round(r["best_us"], 1), candidates=r["tried"],
+                        tflops=round(2.0 * r["M"] * r["N"] * r["K"] / r["best_us"] / 1e6, 1),
+                        weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2)) for r in engine.gemm_report],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         engine.shutdown()

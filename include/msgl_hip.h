@@ -20,9 +20,10 @@
  *     inside hipGraph stream capture;
  *   - strides are in ELEMENTS of the tensor dtype unless the name says bytes.
  *
- * Two shared objects implement it:
- *   libmsgl_hip.so   everything except the communicator (no RCCL dependency)
+ * Three shared objects implement it:
+ *   libmsgl_hip.so   every hand-written kernel + host helpers (no library dependency)
  *   libmsgl_comm.so  msgl_comm_* (links librccl)
+ *   libmsgl_gemm.so  msgl_gemm_* (links libhipblaslt)
  */
 #ifndef MSGL_HIP_H_
 #define MSGL_HIP_H_
@@ -45,7 +46,7 @@ extern "C" {
 /* dtype codes for logits */
 #define MSGL_F32 2
 
-#define MSGL_ABI_VERSION 1
+#define MSGL_ABI_VERSION 2
 
 /* Last error message of the calling thread ("" if none). */
 const char* msgl_last_error(void);
@@ -143,6 +144,7 @@ int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, i
  *   msgl_attn_decode_plan      once per step (seq_lens -> work list)
  *   msgl_attn_decode           once per layer (partial attention + merge)
  * Both are capture-safe; grids are fixed by (max_bs, capacity).
+ * min_chunk of the plan must be a multiple of 16 (tiles stay 16-aligned).
  * ---------------------------------------------------------------------- */
 /* number of int32 words the plan buffer needs */
 int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);
@@ -155,7 +157,11 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
                      const int32_t* seq_lens, const int32_t* plan, void* workspace, int batch,
                      int max_bs, int capacity, int num_q_heads, int num_kv_heads, int head_dim,
                      int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
-                     int64_t out_stride_tok, float sm_scale, int dtype, void* stream);
+                     int64_t out_stride_tok, float sm_scale, int slot_run, int dtype, void* stream);
+/* slot_run: the caller's guarantee that every ALIGNED run of slot_run positions of a request maps to
+ * consecutive token slots (= the engine's page_size under the reference's page-aligned allocation,
+ * P/scheduler/cache.py:42-53,127-146; the property fa.py:92-97 relies on).  1 = no guarantee.
+ * With slot_run >= 16 the kernel reads one table entry per 16-token tile through the scalar cache. */
 
 /* ------------------------------------------------------------------------
  * Paged varlen causal prefill attention (MFMA).  Replaces the prefill phase
@@ -211,6 +217,30 @@ int msgl_comm_all_gather(msgl_comm_t comm, void* dst, const void* src, size_t co
 void* msgl_comm_get_buffer(msgl_comm_t comm);
 int msgl_comm_destroy(msgl_comm_t comm);
 const char* msgl_comm_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Projection GEMMs (libmsgl_gemm.so, links libhipblaslt).  Replaces the
+ * `F.linear` call sites of the reference (P/layers/linear.py:32,103,124,
+ * P/layers/embedding.py:98): out[M, N] = x[M, K] . w[N, K]^T, row-major,
+ * bf16/fp16 in and out, fp32 accumulate; ld* are row strides in elements.
+ * msgl_gemm_nt launches the solution remembered for the shape (the library's
+ * heuristic pick until msgl_gemm_tune has run for it) with the caller's
+ * workspace: no allocation, no sync.  msgl_gemm_tune times library solutions
+ * on `n_w` rotating weight buffers (max_candidates: 0 = all, n > 1 = first n,
+ * -n = heuristic top n, 1 = heuristic pick only), remembers the fastest and
+ * SYNCHRONISES (initialisation-time call, not capturable).
+ * ---------------------------------------------------------------------- */
+int msgl_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
+                 int64_t ldw, int64_t ldo, int dtype, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w, int M, int N,
+                   int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, void* workspace,
+                   int64_t workspace_bytes, int max_candidates, int iters, float* best_us,
+                   float* default_us, int* best_index, int* n_tried, void* stream);
+/* kernel name of the remembered solution into buf; returns its library index (< 0 on error) */
+int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype,
+                            char* buf, int buf_len);
+const char* msgl_gemm_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -18,11 +18,12 @@ _PKG = Path(__file__).resolve().parent
 LIB_DIR = _PKG / "lib"
 HIP_SO = LIB_DIR / "libmsgl_hip.so"
 COMM_SO = LIB_DIR / "libmsgl_comm.so"
+GEMM_SO = LIB_DIR / "libmsgl_gemm.so"
 
 BF16, FP16, F32 = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 PREFILL_QTILE = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _u64, _sz = C.c_uint64, C.c_size_t
@@ -48,7 +49,7 @@ HIP_SIGNATURES = {
     "msgl_attn_decode_plan": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "msgl_attn_decode": (
         _i,
-        [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p],
+        [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _i, _p],
     ),
     "msgl_attn_prefill": (
         _i,
@@ -67,6 +68,18 @@ COMM_SIGNATURES = {
     "msgl_comm_get_buffer": (_p, [_p]),
     "msgl_comm_destroy": (_i, [_p]),
     "msgl_comm_last_error": (C.c_char_p, []),
+}
+
+
+GEMM_SIGNATURES = {
+    "msgl_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
+    "msgl_gemm_tune": (
+        _i,
+        [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _l, _l, _l, _i, _p, _l, _i, _i, C.POINTER(_f), C.POINTER(_f),
+         C.POINTER(_i), C.POINTER(_i), _p],
+    ),
+    "msgl_gemm_solution_name": (_i, [_i, _i, _i, _l, _l, _l, _i, C.c_char_p, _i]),
+    "msgl_gemm_last_error": (C.c_char_p, []),
 }
 
 
@@ -104,6 +117,7 @@ def _missing(name: str, path: Path):
 
 _hip: C.CDLL | None = None
 _comm: C.CDLL | None = None
+_gemm: C.CDLL | None = None
 
 
 def lib() -> C.CDLL:
@@ -120,6 +134,19 @@ def comm_lib() -> C.CDLL:
     if _comm is None:
         _comm = _bind(COMM_SO, COMM_SIGNATURES)
     return _comm
+
+
+def gemm_lib() -> C.CDLL:
+    global _gemm
+    if _gemm is None:
+        _gemm = _bind(GEMM_SO, GEMM_SIGNATURES)
+    return _gemm
+
+
+def check_gemm(rc: int, what: str = "") -> None:
+    if rc < 0:
+        msg = gemm_lib().msgl_gemm_last_error().decode(errors="replace")
+        raise MsglError(f"{what or 'msgl gemm call'} failed ({rc}): {msg}")
 
 
 def check(rc: int, what: str = "") -> None:

@@ -47,6 +47,8 @@ class HipAttnBackend:
         self.config = config
         self.kvcache = ctx.kv_cache
         self.page_size = ctx.page_size
+        # aligned runs of this many positions never cross a page => consecutive slots (cache.py:42-53)
+        self.slot_run = self.page_size & -self.page_size
         self.device = self.kvcache.device
         self.head_dim = config.head_dim
         self.scale = config.head_dim ** -0.5
@@ -86,7 +88,7 @@ class HipAttnBackend:
         table = self.ctx.page_table
         if md.max_seqlen_q == 1:
             ops.attn_decode(out, q, k_tok, v_tok, table, md.req_rows, md.seq_lens, md.plan, self._workspace,
-                            md.batch, self.max_bs, self.capacity, self.scale)
+                            md.batch, self.max_bs, self.capacity, self.scale, slot_run=self.slot_run)
         else:
             ops.attn_prefill(out, q, k_tok, v_tok, table, md.req_rows, md.seq_lens, md.cu_seqlens_q, md.tile_cu,
                              md.batch, md.total_tiles, self.scale)

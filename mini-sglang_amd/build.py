@@ -6,6 +6,7 @@
 Outputs (git-ignored, shipped to the GPU box by gpurun because they are in-tree):
     mini-sglang_amd/lib/libmsgl_hip.so    every kernel + host helpers   (include/msgl_hip.h)
     mini-sglang_amd/lib/libmsgl_comm.so   RCCL communicator             (links librccl)
+    mini-sglang_amd/lib/libmsgl_gemm.so   projection GEMMs + tuner      (links libhipblaslt)
 
 hipcc cross-compiles for gfx950 without a GPU, so this also runs in the build container.
 """
@@ -35,6 +36,7 @@ HIP_SOURCES = [
     "sampling.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]
+GEMM_SOURCES = ["gemm.cpp"]
 
 COMMON_FLAGS = [
     "-O3",
@@ -77,9 +79,12 @@ def build_all(force: bool = False, verbose: bool = True) -> dict[str, Path]:
     OBJ.mkdir(exist_ok=True)
     hip_srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
     comm_srcs = [CSRC / s for s in COMM_SOURCES if (CSRC / s).exists()]
+    gemm_srcs = [CSRC / s for s in GEMM_SOURCES if (CSRC / s).exists()]
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(lambda s: _compile(s, force), hip_srcs + comm_srcs))
-    hip_objs, comm_objs = objs[: len(hip_srcs)], objs[len(hip_srcs):]
+        objs = list(pool.map(lambda s: _compile(s, force), hip_srcs + comm_srcs + gemm_srcs))
+    hip_objs = objs[: len(hip_srcs)]
+    comm_objs = objs[len(hip_srcs): len(hip_srcs) + len(comm_srcs)]
+    gemm_objs = objs[len(hip_srcs) + len(comm_srcs):]
     out = {}
     lib_hip = LIB / "libmsgl_hip.so"
     if force or _stale(lib_hip, hip_objs):
@@ -91,6 +96,12 @@ def build_all(force: bool = False, verbose: bool = True) -> dict[str, Path]:
             _run([HIPCC, "-shared", "-fPIC", *map(str, comm_objs), "-L", str(ROCM / "lib"), "-lrccl",
                   f"-Wl,-rpath,{ROCM / 'lib'}", "-o", str(lib_comm)])
         out["comm"] = lib_comm
+    if gemm_objs:
+        lib_gemm = LIB / "libmsgl_gemm.so"
+        if force or _stale(lib_gemm, gemm_objs):
+            _run([HIPCC, "-shared", "-fPIC", *map(str, gemm_objs), "-L", str(ROCM / "lib"), "-lhipblaslt",
+                  f"-Wl,-rpath,{ROCM / 'lib'}", "-o", str(lib_gemm)])
+        out["gemm"] = lib_gemm
     if verbose:
         for k, v in out.items():
             print(f"[build] {k}: {v} ({v.stat().st_size >> 10} KiB)")

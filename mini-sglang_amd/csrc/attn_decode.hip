@@ -24,6 +24,24 @@
 
 namespace msgl {
 
+// Order pins.  hipcc on its own sinks the next tile's global loads behind the compute block (and
+// floats the pure q.k dots up to the loads), which drains vmcnt(0) at the loop top and leaves nothing
+// in flight while the wave computes.  MSGL_PIN_MEM: an empty asm with a memory clobber keeps the plain
+// C++ loads on their side at IR level, sched_barrier(0) does the same in the machine scheduler.
+// pin_tile() additionally routes a tile's registers through the asm, so nothing that consumes the
+// tile can be placed before that point.  vmcnt bookkeeping stays with the compiler.
+#define MSGL_PIN_MEM()                      \
+  do {                                      \
+    asm volatile("" ::: "memory");          \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+
+typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+typedef int I16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(4))) int CInt;                                // constant address space
+typedef int I16a __attribute__((ext_vector_type(16), aligned(16)));
+typedef __attribute__((address_space(4))) I16a CI16;
+
 constexpr int kPlanHdr = 4;  // [0] n_items [1] chunk [2] batch [3] reserved
 constexpr float kNegBig = -3.0e38f;
 
@@ -117,15 +135,25 @@ struct DecodeParams {
   float* part_ml;
   int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
   int max_bs, hq, hv, group;  // hv = virtual kv heads (hq / G), group = hq / real kv heads
+  int slot_run;               // aligned runs of this many positions map to consecutive slots (1: none)
   float scale_log2;
 };
 
 struct Tile {
-  U4 k[4], v[4];
+  V4 k[4], v[4];
 };
 
-template <typename T, int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) {
+__device__ __forceinline__ void pin_tile(Tile& t) {
+  asm volatile(""
+               : "+v"(t.k[0]), "+v"(t.k[1]), "+v"(t.k[2]), "+v"(t.k[3]), "+v"(t.v[0]), "+v"(t.v[1]),
+                 "+v"(t.v[2]), "+v"(t.v[3])
+               :
+               : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int G, bool kRun>
+__global__ __launch_bounds__(256, (G <= 5 ? 2 : 1)) void attn_decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
   const int lane = threadIdx.x & 63;
   const int r = lane >> 4;  // DPP row = token sub-slot
@@ -163,6 +191,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
     }
     const uint16_t* kb = p.k + (int64_t)kvh * p.kv_stride_head + c * 8;
     const uint16_t* vb = p.v + (int64_t)kvh * p.kv_stride_head + c * 8;
+    const uint16_t* kb_row = kb + (int64_t)(4 * r) * p.kv_stride_tok;  // kRun: lane row r starts 4r tokens in
+    const uint16_t* vb_row = vb + (int64_t)(4 * r) * p.kv_stride_tok;
 
     float m[G], l[G], o[G][8];
 #pragma unroll
@@ -173,23 +203,71 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
       for (int e = 0; e < 8; ++e) o[g][e] = 0.f;
     }
 
-    // slots of tokens tb+4r .. tb+4r+3; entries at or past t1 are never dereferenced
-    auto load_slots = [&](int tb) -> int4 {
-      int tq = tb + 4 * r;
-      if (tq >= t1) tq = tb;
-      int4 s = *reinterpret_cast<const int4*>(pt + tq);
-      if (tq + 1 >= t1) s.y = s.x;
-      if (tq + 2 >= t1) s.z = s.x;
-      if (tq + 3 >= t1) s.w = s.x;
-      return s;
+    // Page-table slots of a 16-token tile (tokens tb+4r+i for lane row r, load i).
+    //  kRun (caller guarantees that every aligned run of 16 positions maps to 16 consecutive slots,
+    //  i.e. page_size >= 16 with the reference's page-aligned allocation, P/scheduler/cache.py:42-53,
+    //  127-146 -- the same property fa.py:92-97 relies on): ONE wave-uniform int per tile, read through
+    //  the scalar cache (constant address space => s_load, lgkmcnt), so the in-order vmcnt queue holds
+    //  K/V loads only and the per-tile address arithmetic is scalar.
+    //  generic: lane row r loads its own 4 slots as one 16-B vector load, issued AFTER the tile's K/V
+    //  loads (vmcnt retires in order: waiting for the older tile must not wait for this load).
+    // Entries at or past t1 are never dereferenced (such tokens re-read the tile's first token).
+    using Slots = std::conditional_t<kRun, int, int4>;
+    const CInt* cpt = (const CInt*)pt;
+    auto slots_raw = [&](int tb) -> Slots {
+      if constexpr (kRun) {
+        return cpt[tb];
+      } else {
+        int tq = tb + 4 * r;
+        if (tq >= t1) tq = tb;
+        return *reinterpret_cast<const int4*>(pt + tq);
+      }
     };
-    auto load_tile = [&](const int4& s, Tile& t) {
-      const int sl[4] = {s.x, s.y, s.z, s.w};
+    auto slots_fix = [&](Slots sl, int tb) -> Slots {
+      if constexpr (kRun) {
+        asm volatile("" : "+s"(sl));  // consumers (scalar address math) must not float above this point
+      } else {
+        int tq = tb + 4 * r;
+        if (tq >= t1) tq = tb;
+        if (tq + 1 >= t1) sl.y = sl.x;
+        if (tq + 2 >= t1) sl.z = sl.x;
+        if (tq + 3 >= t1) sl.w = sl.x;
+      }
+      return sl;
+    };
+    auto load_slots = [&](int tb) -> Slots { return slots_fix(slots_raw(tb), tb); };
+    // full tile: every token valid
+    auto load_tile = [&](const Slots& sl, Tile& t) {
+      if constexpr (kRun) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t off = (int64_t)sl[i] * p.kv_stride_tok;
-        t.k[i] = ldg16(kb + off);
-        t.v[i] = ldg16(vb + off);
+        for (int i = 0; i < 4; ++i) {
+          const int64_t off = (int64_t)(sl + i) * p.kv_stride_tok;  // scalar
+          t.k[i] = *reinterpret_cast<const V4*>(kb_row + off);
+          t.v[i] = *reinterpret_cast<const V4*>(vb_row + off);
+        }
+      } else {
+        const int v[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t off = (int64_t)v[i] * p.kv_stride_tok;
+          t.k[i] = *reinterpret_cast<const V4*>(kb + off);
+          t.v[i] = *reinterpret_cast<const V4*>(vb + off);
+        }
+      }
+    };
+    // possibly partial tile (the unit's last one)
+    auto load_tile_tail = [&](const Slots& sl, Tile& t, int tb) {
+      if constexpr (kRun) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int tk = 4 * r + i;
+          if (tb + tk >= t1) tk = 0;
+          const int64_t off = (int64_t)(sl + tk) * p.kv_stride_tok;
+          t.k[i] = *reinterpret_cast<const V4*>(kb + off);
+          t.v[i] = *reinterpret_cast<const V4*>(vb + off);
+        }
+      } else {
+        load_tile(sl, t);
       }
     };
     auto compute = [&](const Tile& t, int tb, auto masked_tag) {
@@ -258,29 +336,45 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
     const int ntiles = (t1 - t0 + 15) >> 4;
     const int last = t0 + (ntiles - 1) * 16;
     Tile A, B;
-    int4 sA = load_slots(t0);
-    load_tile(sA, A);
-    int4 sB = load_slots(min(t0 + 16, last));
+    Slots sA = load_slots(t0);
+    if (ntiles > 1) load_tile(sA, A);
+    else load_tile_tail(sA, A, t0);
+    Slots sB = load_slots(min(t0 + 16, last));
     int tix = 0;
-    // steady state: tiles tix and tix+1 are full (tix+2 exists), no branches inside
-    for (; tix + 2 < ntiles; tix += 2) {
+    // steady state: tiles tix and tix+1 are full (tix+2 exists), no branches inside.
+    // order per half: issue the next tile's loads, pin, compute the resident tile (see MSGL_PIN_MEM)
+    for (; tix + 3 < ntiles; tix += 2) {
       const int tb = t0 + tix * 16;
+      const int tb3 = min(tb + 48, last);
+      Slots rawA, rawB;
+      if constexpr (kRun) rawA = slots_raw(tb + 32);
       load_tile(sB, B);
-      sA = load_slots(tb + 32);
+      if constexpr (!kRun) rawA = slots_raw(tb + 32);
+      pin_tile(A);  // waits for A only: B (issued just above) stays in flight under compute(A)
       compute(A, tb, Full{});
-      load_tile(sA, A);
-      sB = load_slots(min(tb + 48, last));
+      MSGL_PIN_MEM();
+      sA = slots_fix(rawA, tb + 32);
+      if constexpr (kRun) rawB = slots_raw(tb3);
+      load_tile(sA, A);  // tile tix+2 is full: tix+3 < ntiles
+      if constexpr (!kRun) rawB = slots_raw(tb3);
+      pin_tile(B);
       compute(B, tb + 16, Full{});
+      MSGL_PIN_MEM();
+      sB = slots_fix(rawB, tb3);
     }
-    {  // one or two tiles left; A holds tile tix
+    // one, two or three tiles left; A holds tile tix, sB the slots of tile tix+1 (if any)
+    for (; tix < ntiles; ++tix) {
       const int tb = t0 + tix * 16;
-      const bool two = tix + 1 < ntiles;
-      if (two) {
-        load_tile(sB, B);
-        compute(A, tb, Full{});
-        compute(B, tb + 16, Masked{});
-      } else {
-        compute(A, tb, Masked{});
+      const bool more = tix + 1 < ntiles;
+      if (more) {
+        if (tix + 2 < ntiles) load_tile(sB, B);
+        else load_tile_tail(sB, B, tb + 16);
+      }
+      if (more) compute(A, tb, Full{});
+      else compute(A, tb, Masked{});
+      if (more) {
+        A = B;
+        sB = load_slots(min(tb + 32, last));
       }
     }
 
@@ -363,12 +457,12 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
   *op = Elem<T>::pack(acc0 * inv, acc1 * inv);
 }
 
-template <typename T, int G>
-static int launch_decode(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+template <typename T, int G, bool kRun>
+static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
   static int blocks_per_cu = 0;
   if (blocks_per_cu == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G>, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, kRun>, 256, 0) != hipSuccess ||
         nb <= 0) {
       (void)hipGetLastError();
       nb = 2;
@@ -381,10 +475,16 @@ static int launch_decode(const DecodeParams& p, int batch, int capacity, hipStre
   const int64_t resident = (int64_t)cus * blocks_per_cu;
   if (blocks > resident) blocks = resident;
   if (blocks < 1) blocks = 1;
-  attn_decode_kernel<T, G><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  attn_decode_kernel<T, G, kRun><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
   const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
   attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
   return MSGL_OK;
+}
+
+template <typename T, int G>
+static int launch_decode(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+  return p.slot_run >= 16 ? launch_decode_run<T, G, true>(p, batch, capacity, s)
+                          : launch_decode_run<T, G, false>(p, batch, capacity, s);
 }
 
 template <typename T>
@@ -459,9 +559,12 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
                                 const int32_t* seq_lens, const int32_t* plan, void* workspace, int batch,
                                 int max_bs, int capacity, int num_q_heads, int num_kv_heads, int head_dim,
                                 int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
-                                int64_t out_stride_tok, float sm_scale, int dtype, void* stream) {
+                                int64_t out_stride_tok, float sm_scale, int slot_run, int dtype,
+                                void* stream) {
   MSGL_REQUIRE(out && q && k_cache && v_cache && page_table && seq_lens && plan && workspace,
                "attn_decode: null pointer");
+  MSGL_REQUIRE(slot_run >= 1 && (slot_run & (slot_run - 1)) == 0, "attn_decode: slot_run %d must be a power of two",
+               slot_run);
   MSGL_REQUIRE(batch >= 1 && batch <= max_bs && capacity >= max_bs, "attn_decode: bad batch/capacity");
   MSGL_REQUIRE(head_dim == 128, "attn_decode: head_dim %d unsupported (128 only)", head_dim);
   MSGL_REQUIRE(num_kv_heads >= 1 && num_q_heads % num_kv_heads == 0, "attn_decode: %d q heads / %d kv heads",
@@ -495,6 +598,7 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
   p.hq = num_q_heads;
   p.hv = num_q_heads / G;
   p.group = group;
+  p.slot_run = slot_run;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;

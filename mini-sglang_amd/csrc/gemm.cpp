@@ -1,0 +1,341 @@
+// Decode/prefill projection GEMMs: a thin C-ABI over the
+// hipBLASLt *library* kernels with a per-shape solution search.
+//
+// The reference leaves these to `F.linear` (P/layers/linear.py:32,103,124, embedding.py:98), i.e.
+// to the BLAS library's default heuristic.  On gfx950 that heuristic is poor for the M <= 256
+// weight-streaming shapes of a decode step (round-1 profile: 1.2-1.4 TB/s of weights,
+// ~350 TFLOP/s at M = 256), so this file
+//   * enumerates every library solution that supports the shape (hipblaslt_ext::getAllAlgos +
+//     matmulIsAlgoSupported), times each on rotating weight buffers (so the 256 MiB Infinity
+//     Cache cannot flatter a candidate: in a real step 28 GB stream between two uses of a
+//     weight) and remembers the fastest per (M, N, K, ld*, dtype);
+//   * launches the remembered solution (or the library's top heuristic for untuned shapes)
+//     with a caller-provided workspace: no allocation, no sync => legal under stream capture.
+// msgl_gemm_tune() itself synchronises and is an initialisation-time call.
+//
+// Layout: out[M, N] = x[M, K] . w[N, K]^T, all row-major (torch `F.linear`); in BLAS column-major
+// terms D^T[N, M] = op_T(W)[N, K] . X^T[K, M]  => m = N, n = M, k = K, transA = T, transB = N.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <hipblaslt/hipblaslt.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/msgl_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define GEMM_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) {              \
+      set_err(__VA_ARGS__);     \
+      return MSGL_EINVAL;       \
+    }                           \
+  } while (0)
+
+#define GEMM_BLAS(call)                                                     \
+  do {                                                                      \
+    hipblasStatus_t st_ = (call);                                           \
+    if (st_ != HIPBLAS_STATUS_SUCCESS) {                                    \
+      set_err("%s failed with hipblasStatus %d (%s:%d)", #call, (int)st_, __FILE__, __LINE__); \
+      return MSGL_ELAUNCH;                                                  \
+    }                                                                       \
+  } while (0)
+
+#define GEMM_HIP(call)                                                      \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      set_err("%s failed: %s", #call, hipGetErrorString(e_));               \
+      return MSGL_ELAUNCH;                                                  \
+    }                                                                       \
+  } while (0)
+
+using Key = std::tuple<int, int, int, int, int64_t, int64_t, int64_t, int>;  // device, M N K, ldx ldw ldo, dtype
+
+struct Problem {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
+  ~Problem() {
+    if (a) hipblasLtMatrixLayoutDestroy(a);
+    if (b) hipblasLtMatrixLayoutDestroy(b);
+    if (d) hipblasLtMatrixLayoutDestroy(d);
+    if (desc) hipblasLtMatmulDescDestroy(desc);
+  }
+};
+
+struct Plan {
+  Problem* prob = nullptr;  // owned for process lifetime
+  hipblasLtMatmulAlgo_t algo;
+  size_t workspace = 0;
+  bool tuned = false;
+  int algo_index = -1;
+};
+
+std::mutex g_mu;
+std::map<int, hipblasLtHandle_t> g_handles;  // per device
+std::map<Key, Plan> g_plans;
+
+int get_handle(hipblasLtHandle_t* h, int* dev_out) {
+  int dev = 0;
+  GEMM_HIP(hipGetDevice(&dev));
+  auto it = g_handles.find(dev);
+  if (it == g_handles.end()) {
+    hipblasLtHandle_t nh;
+    GEMM_BLAS(hipblasLtCreate(&nh));
+    it = g_handles.emplace(dev, nh).first;
+  }
+  *h = it->second;
+  *dev_out = dev;
+  return MSGL_OK;
+}
+
+int make_problem(Problem* p, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype) {
+  const hipDataType t = dtype == MSGL_BF16 ? HIP_R_16BF : HIP_R_16F;
+  GEMM_BLAS(hipblasLtMatmulDescCreate(&p->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  const int32_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+  GEMM_BLAS(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
+  GEMM_BLAS(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
+  // A = W stored [N][K] row-major = column-major K x N with ld = ldw (used transposed)
+  GEMM_BLAS(hipblasLtMatrixLayoutCreate(&p->a, t, (uint64_t)K, (uint64_t)N, ldw));
+  // B = X stored [M][K] row-major = column-major K x M with ld = ldx
+  GEMM_BLAS(hipblasLtMatrixLayoutCreate(&p->b, t, (uint64_t)K, (uint64_t)M, ldx));
+  // D = out stored [M][N] row-major = column-major N x M with ld = ldo
+  GEMM_BLAS(hipblasLtMatrixLayoutCreate(&p->d, t, (uint64_t)N, (uint64_t)M, ldo));
+  return MSGL_OK;
+}
+
+int check_args(const void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+               int64_t ldo, int dtype) {
+  GEMM_REQUIRE(out && x && w, "gemm: null pointer");
+  GEMM_REQUIRE(M >= 1 && N >= 1 && K >= 1, "gemm: bad shape %d x %d x %d", M, N, K);
+  GEMM_REQUIRE(ldx >= K && ldw >= K && ldo >= N, "gemm: leading dimensions (%lld, %lld, %lld) too small",
+               (long long)ldx, (long long)ldw, (long long)ldo);
+  GEMM_REQUIRE(dtype == MSGL_BF16 || dtype == MSGL_FP16, "gemm: unsupported dtype code %d", dtype);
+  return MSGL_OK;
+}
+
+int run(hipblasLtHandle_t h, const Plan& pl, void* out, const void* x, const void* w, void* ws, size_t ws_bytes,
+        hipStream_t s) {
+  const float alpha = 1.0f, beta = 0.0f;
+  if (pl.workspace > ws_bytes) {
+    set_err("gemm: solution needs %zu workspace bytes, caller gave %zu", pl.workspace, ws_bytes);
+    return MSGL_EINVAL;
+  }
+  GEMM_BLAS(hipblasLtMatmul(h, pl.prob->desc, &alpha, w, pl.prob->a, x, pl.prob->b, &beta, out, pl.prob->d, out,
+                            pl.prob->d, &pl.algo, ws, ws_bytes, s));
+  return MSGL_OK;
+}
+
+// heuristic top-1 under the workspace limit
+int heuristic_plan(hipblasLtHandle_t h, Plan* pl, size_t ws_bytes) {
+  hipblasLtMatmulPreference_t pref;
+  GEMM_BLAS(hipblasLtMatmulPreferenceCreate(&pref));
+  uint64_t lim = ws_bytes;
+  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &lim, sizeof(lim));
+  hipblasLtMatmulHeuristicResult_t res[1];
+  int n = 0;
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(h, pl->prob->desc, pl->prob->a, pl->prob->b, pl->prob->d,
+                                                       pl->prob->d, pref, 1, res, &n);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || n < 1) {
+    set_err("gemm: the library has no solution for this shape (status %d)", (int)st);
+    return MSGL_EINVAL;
+  }
+  pl->algo = res[0].algo;
+  pl->workspace = res[0].workspaceSize;
+  pl->algo_index = hipblaslt_ext::getIndexFromAlgo(pl->algo);
+  return MSGL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* msgl_gemm_last_error(void) { return g_err; }
+
+int msgl_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                 int64_t ldo, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_args(out, x, w, M, N, K, ldx, ldw, ldo, dtype);
+  if (rc != MSGL_OK) return rc;
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  if ((rc = get_handle(&h, &dev)) != MSGL_OK) return rc;
+  const size_t ws_bytes = workspace ? (size_t)std::max<int64_t>(workspace_bytes, 0) : 0;
+  const Key key{dev, M, N, K, ldx, ldw, ldo, dtype};
+  auto it = g_plans.find(key);
+  if (it == g_plans.end()) {
+    Plan pl;
+    pl.prob = new Problem();
+    if ((rc = make_problem(pl.prob, M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
+    if ((rc = heuristic_plan(h, &pl, ws_bytes)) != MSGL_OK) return rc;
+    it = g_plans.emplace(key, pl).first;
+  }
+  return run(h, it->second, out, x, w, workspace, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w, int M, int N, int K, int64_t ldx,
+                   int64_t ldw, int64_t ldo, int dtype, void* workspace, int64_t workspace_bytes,
+                   int max_candidates, int iters, float* best_us, float* default_us, int* best_index,
+                   int* n_tried, void* stream) {
+  GEMM_REQUIRE(w_list && n_w >= 1, "gemm_tune: need at least one weight buffer");
+  int rc = check_args(out, x, w_list[0], M, N, K, ldx, ldw, ldo, dtype);
+  if (rc != MSGL_OK) return rc;
+  if (iters < 1) iters = 1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  if ((rc = get_handle(&h, &dev)) != MSGL_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t ws_bytes = workspace ? (size_t)std::max<int64_t>(workspace_bytes, 0) : 0;
+
+  Plan base;
+  base.prob = new Problem();
+  if ((rc = make_problem(base.prob, M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
+  if ((rc = heuristic_plan(h, &base, ws_bytes)) != MSGL_OK) return rc;
+
+  const hipDataType t = dtype == MSGL_BF16 ? HIP_R_16BF : HIP_R_16F;
+  // max_candidates: 0 = every library solution, n > 1 = the first n of them, -n = the top n of the
+  // library's own heuristic ranking (cheap: tens of candidates), 1 = heuristic pick only
+  std::vector<hipblasLtMatmulHeuristicResult_t> all;
+  if (max_candidates == 0 || max_candidates > 1) {
+    hipblasStatus_t st = hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T,
+                                                    HIPBLAS_OP_N, t, t, t, t, HIPBLAS_COMPUTE_32F, all);
+    if (st != HIPBLAS_STATUS_SUCCESS) all.clear();
+  } else if (max_candidates < 0) {
+    hipblasLtMatmulPreference_t pref;
+    GEMM_BLAS(hipblasLtMatmulPreferenceCreate(&pref));
+    uint64_t lim = ws_bytes;
+    hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &lim, sizeof(lim));
+    all.resize((size_t)(-max_candidates));
+    int n = 0;
+    hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(h, base.prob->desc, base.prob->a, base.prob->b,
+                                                         base.prob->d, base.prob->d, pref, -max_candidates,
+                                                         all.data(), &n);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    all.resize(st == HIPBLAS_STATUS_SUCCESS ? (size_t)std::max(n, 0) : 0);
+    max_candidates = 0;
+  }
+  // candidate 0 is always the library's own heuristic pick (= what F.linear would run)
+  std::vector<Plan> cands;
+  cands.push_back(base);
+  const float alpha = 1.0f, beta = 0.0f;
+  for (auto& r : all) {
+    if (max_candidates > 0 && (int)cands.size() >= max_candidates) break;
+    size_t need = 0;
+    if (hipblaslt_ext::matmulIsAlgoSupported(h, base.prob->desc, &alpha, base.prob->a, base.prob->b, &beta,
+                                             base.prob->d, base.prob->d, r.algo, need) != HIPBLAS_STATUS_SUCCESS)
+      continue;
+    if (need > ws_bytes) continue;
+    Plan c = base;
+    c.algo = r.algo;
+    c.workspace = need;
+    c.algo_index = hipblaslt_ext::getIndexFromAlgo(c.algo);
+    if (c.algo_index == base.algo_index) continue;
+    cands.push_back(c);
+  }
+
+  hipEvent_t e0, e1;
+  GEMM_HIP(hipEventCreate(&e0));
+  GEMM_HIP(hipEventCreate(&e1));
+  auto time_us = [&](const Plan& c, int reps, float* us) -> int {
+    int r0 = run(h, c, out, x, w_list[0], workspace, ws_bytes, s);  // warm-up (code object load)
+    if (r0 != MSGL_OK) return r0;
+    if (hipEventRecord(e0, s) != hipSuccess) return MSGL_ELAUNCH;
+    for (int i = 0; i < reps; ++i) {
+      r0 = run(h, c, out, x, w_list[(i + 1) % n_w], workspace, ws_bytes, s);
+      if (r0 != MSGL_OK) return r0;
+    }
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return MSGL_ELAUNCH;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return MSGL_ELAUNCH;
+    *us = ms * 1e3f / reps;
+    return MSGL_OK;
+  };
+
+  // pass 1: a short timing of every candidate; pass 2: re-time the best few with full iters
+  std::vector<std::pair<float, int>> ranked;
+  const int quick = std::max(2, std::min(iters, 4));
+  for (int i = 0; i < (int)cands.size(); ++i) {
+    float us = 0.f;
+    if (time_us(cands[i], quick, &us) != MSGL_OK) {
+      (void)hipGetLastError();
+      continue;
+    }
+    ranked.emplace_back(us, i);
+  }
+  if (ranked.empty()) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    set_err("gemm_tune: no candidate ran");
+    return MSGL_ELAUNCH;
+  }
+  std::sort(ranked.begin(), ranked.end());
+  float best = 1e30f, def = -1.f;
+  int best_i = 0;
+  const int finals = std::min<int>(8, ranked.size());
+  for (int r = 0; r < finals; ++r) {
+    float us = 0.f;
+    if (time_us(cands[ranked[r].second], iters, &us) != MSGL_OK) continue;
+    if (ranked[r].second == 0) def = us;
+    if (us < best) {
+      best = us;
+      best_i = ranked[r].second;
+    }
+  }
+  if (def < 0.f) {
+    float us = 0.f;
+    if (time_us(cands[0], iters, &us) == MSGL_OK) def = us;
+    if (def >= 0.f && def < best) {
+      best = def;
+      best_i = 0;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+
+  Plan chosen = cands[best_i];
+  chosen.tuned = true;
+  const Key key{dev, M, N, K, ldx, ldw, ldo, dtype};
+  g_plans[key] = chosen;  // base.prob stays alive (shared by the map entry)
+  if (best_us) *best_us = best;
+  if (default_us) *default_us = def;
+  if (best_index) *best_index = chosen.algo_index;
+  if (n_tried) *n_tried = (int)ranked.size();
+  return MSGL_OK;
+}
+
+int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, char* buf,
+                            int buf_len) {
+  GEMM_REQUIRE(buf && buf_len > 0, "gemm_solution_name: bad buffer");
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  int rc = get_handle(&h, &dev);
+  if (rc != MSGL_OK) return rc;
+  auto it = g_plans.find(Key{dev, M, N, K, ldx, ldw, ldo, dtype});
+  GEMM_REQUIRE(it != g_plans.end(), "gemm_solution_name: shape not planned yet");
+  std::string name = hipblaslt_ext::getKernelNameFromAlgo(h, it->second.algo);
+  snprintf(buf, (size_t)buf_len, "%s%s", it->second.tuned ? "[tuned] " : "[heuristic] ", name.c_str());
+  return it->second.algo_index;
+}
+
+}  // extern "C"

@@ -85,6 +85,7 @@ class EngineConfig:
     num_page_override: Optional[int] = None
     fused_qkv_path: bool = True
     comm: Any = None  # RcclCommunicator (tp_size > 1)
+    gemm_tune: str = "heuristic"  # "off" | "heuristic" | "full": library solution search per graph batch size
     seed: int = 42
 
     @property
@@ -220,6 +221,8 @@ class Engine:
         self.page_table[self.dummy_req.table_idx].fill_(num_tokens)  # the dummy page
         bs_list = determine_graph_bs(cfg.cuda_graph_bs, cfg.cuda_graph_max_bs, free_before)
         bs_list = [b for b in bs_list if b <= cfg.max_running_req]
+        # solution search happens before capture (it synchronises); full search only where it pays
+        self.gemm_report = self.model.tune_gemms(bs_list, cfg.gemm_tune)
         self.graph_runner = GraphRunner(self, bs_list)
 
     def forward_batch(self, batch: Batch, args: BatchSamplingArgs) -> ForwardOutput:

@@ -4,8 +4,9 @@ This is the caller of the path, restated compactly from the reference's composit
 (P/models/qwen3.py:18-81, P/models/llama.py, P/models/utils.py:25-123, P/layers/*): the
 reference's own model classes run unchanged on top of the plugin; this copy
 exists because /root/reference is not present on the GPU box and bench.py / smoke need a
-driver.  GEMMs stay `F.linear` (hipBLASLt), exactly as in the reference (P/layers/linear.py:32);
-everything else goes through the gfx950 kernels.
+driver.  GEMMs are the library's (hipBLASLt) as in the reference (P/layers/linear.py:32), reached through
+msgl_gemm_nt so that the per-shape solution search of csrc/gemm.cpp applies (`tune_gemms`); everything
+else goes through the hand-written gfx950 kernels.
 
 Two execution modes, bit-identical by construction (tests/test_gpu_model.py):
   fused=False  the reference's op order through its seams: q_norm, k_norm, rope (flashinfer
@@ -18,7 +19,6 @@ from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import flashinfer_compat as fi
 from . import ops
@@ -156,6 +156,33 @@ class DenseDecoder:
             b -= self.embed.numel() * self.embed.element_size()
         return b
 
+    # ------------------------------------------------------------------ GEMM solution search
+    def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None) -> List[dict]:
+        """Pick the fastest library solution for the five projection shapes at each decode batch size
+        (SURVEY.md section 8f rank 2).  mode: "off", "heuristic" (library's top 16), "full" (every
+        solution).  Weights of different layers are rotated so candidates are timed from HBM."""
+        if mode == "off" or not batch_sizes:
+            return []
+        cand = {"heuristic": -16, "full": 0}[mode]
+        report = []
+        step = max(1, len(self.layers) // 8)
+        pick = self.layers[::step][:8]
+        groups = [("qkv", [l.qkv for l in pick], self.cfg.hidden_size),
+                  ("o", [l.o for l in pick], self.q_dim),
+                  ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size),
+                  ("down", [l.down for l in pick], self.inter),
+                  ("lm_head", [self.lm_head], self.cfg.hidden_size)]
+        for bs in batch_sizes:
+            for name, ws, k in groups:
+                x = torch.randn((bs, k), device=self.device, dtype=torch.float32).to(self.dtype)
+                r = ops.gemm_tune(x, ws, max_candidates=cand, iters=8)
+                r["name"] = name
+                report.append(r)
+                if log is not None:
+                    log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "
+                        f"({r['tried']} candidates) {r['kernel'][:100]}")
+        return report
+
     # ------------------------------------------------------------------ forward
     def forward(self, ctx: Any, batch: Any) -> torch.Tensor:
         """P/models/qwen3.py:77-81 -> logits [B, vocab] (model dtype)."""
@@ -171,7 +198,7 @@ class DenseDecoder:
                 x = fi.rmsnorm(x, lw.input_norm, cfg.rms_norm_eps)
             else:
                 fi.fused_add_rmsnorm(x, residual, lw.input_norm, cfg.rms_norm_eps)
-            qkv = F.linear(x, lw.qkv)
+            qkv = ops.linear(x, lw.qkv)
             q, k, v = qkv.split([self.q_dim, self.kv_dim, self.kv_dim], dim=-1)
             if self.fused:
                 kc, vc = kv.k_cache(li), kv.v_cache(li)
@@ -186,17 +213,17 @@ class DenseDecoder:
                 fi.apply_rope_with_cos_sin_cache_inplace(positions=batch.positions, query=q, key=k, head_size=D,
                                                          cos_sin_cache=self.cos_sin)
                 o = backend.forward(q.view(-1, self.hq, D), k, v, li, batch)
-            x = self.comm.all_reduce(F.linear(o.view(-1, self.q_dim), lw.o))
+            x = self.comm.all_reduce(ops.linear(o.view(-1, self.q_dim), lw.o))
             fi.fused_add_rmsnorm(x, residual, lw.post_norm, cfg.rms_norm_eps)
-            gate_up = F.linear(x, lw.gate_up)
+            gate_up = ops.linear(x, lw.gate_up)
             y = fi.silu_and_mul(gate_up)
-            x = self.comm.all_reduce(F.linear(y, lw.down))
+            x = self.comm.all_reduce(ops.linear(y, lw.down))
         fi.fused_add_rmsnorm(x, residual, self.final_norm, cfg.rms_norm_eps)
         # LM head (P/layers/embedding.py:88-110)
         bs = batch.size
         if batch.is_prefill:
             x = x[batch.attn_metadata.get_last_indices(bs)].contiguous()
-        logits = F.linear(x, self.lm_head)
+        logits = ops.linear(x, self.lm_head)
         if self.tp_size == 1:
             return logits
         return lm_head_unshard(self.comm.all_gather(logits), self.tp_size, logits.shape[0], cfg.vocab_size)

@@ -222,8 +222,9 @@ def attn_decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, batch: int, max
 def attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                 page_table: torch.Tensor, req_rows: Optional[torch.Tensor], seq_lens: torch.Tensor,
                 plan: torch.Tensor, workspace: torch.Tensor, batch: int, max_bs: int, capacity: int,
-                sm_scale: float) -> None:
-    """q: [B, Hq, D] (token stride free), k_cache/v_cache: [slots, Hkv, D], out: [B, Hq, D]."""
+                sm_scale: float, slot_run: int = 1) -> None:
+    """q: [B, Hq, D] (token stride free), k_cache/v_cache: [slots, Hkv, D], out: [B, Hq, D].
+    slot_run: aligned runs of this many positions map to consecutive slots (the engine's page_size)."""
     _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, plan, workspace)
     assert q.dim() == 3 and k_cache.dim() == 3 and out.dim() == 3
     hq, d = q.shape[1], q.shape[2]
@@ -237,7 +238,7 @@ def attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cac
             out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), page_table.data_ptr(),
             page_table.stride(0), req_rows.data_ptr() if req_rows is not None else None, seq_lens.data_ptr(),
             plan.data_ptr(), workspace.data_ptr(), batch, max_bs, capacity, hq, hkv, d, q.stride(0),
-            k_cache.stride(0), k_cache.stride(1), out.stride(0), float(sm_scale), _dt(q), _stream(),
+            k_cache.stride(0), k_cache.stride(1), out.stride(0), float(sm_scale), int(slot_run), _dt(q), _stream(),
         ),
         "attn_decode",
     )
@@ -309,3 +310,72 @@ def sample_top_k_top_p(probs: torch.Tensor, top_k: Optional[torch.Tensor], top_p
         "sample_top_k_top_p",
     )
     return out
+
+
+# ---------------------------------------------------------------------------- projection GEMMs
+_GEMM_WS: dict = {}
+GEMM_WORKSPACE_BYTES = 128 << 20  # stream-K / split-K solutions need scratch; one buffer per device
+
+
+def gemm_workspace(device: torch.device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        ws = torch.empty(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _GEMM_WS[key] = ws
+    return ws
+
+
+def _gemm_args(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]):
+    _need_cuda(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], (x.shape, w.shape)
+    assert x.dtype == w.dtype and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == x.dtype and out.is_cuda
+    return out, M, N, K
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T (the reference's `F.linear`, P/layers/linear.py:32) through
+    msgl_gemm_nt: the tuned library solution for the shape if gemm_tune() ran, else the heuristic."""
+    out, M, N, K = _gemm_args(x, w, out)
+    if M == 0:
+        return out
+    ws = gemm_workspace(x.device)
+    _lib.check_gemm(
+        _lib.gemm_lib().msgl_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                     out.stride(0), _dt(x), ws.data_ptr(), ws.numel(), _stream()),
+        "gemm_nt",
+    )
+    return out
+
+
+def gemm_tune(x: torch.Tensor, weights, out: Optional[torch.Tensor] = None, max_candidates: int = 0,
+              iters: int = 10) -> dict:
+    """Search the library's solutions for x @ w^T over the same-shaped `weights` (rotated so the
+    Infinity Cache cannot hold them) and remember the fastest.  Synchronises; call before capture."""
+    import ctypes as C
+
+    weights = list(weights)
+    w0 = weights[0]
+    out, M, N, K = _gemm_args(x, w0, out)
+    for w in weights:
+        assert w.shape == w0.shape and w.stride() == w0.stride() and w.dtype == w0.dtype and w.is_cuda
+    ws = gemm_workspace(x.device)
+    ptrs = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+    best, default = C.c_float(0), C.c_float(0)
+    idx, tried = C.c_int(-1), C.c_int(0)
+    _lib.check_gemm(
+        _lib.gemm_lib().msgl_gemm_tune(out.data_ptr(), x.data_ptr(), ptrs, len(weights), M, N, K, x.stride(0),
+                                       w0.stride(0), out.stride(0), _dt(x), ws.data_ptr(), ws.numel(),
+                                       max_candidates, iters, C.byref(best), C.byref(default), C.byref(idx),
+                                       C.byref(tried), _stream()),
+        "gemm_tune",
+    )
+    buf = C.create_string_buffer(512)
+    _lib.gemm_lib().msgl_gemm_solution_name(M, N, K, x.stride(0), w0.stride(0), out.stride(0), _dt(x), buf, 512)
+    return dict(M=M, N=N, K=K, best_us=best.value, default_us=default.value, index=idx.value, tried=tried.value,
+                kernel=buf.value.decode(errors="replace"))

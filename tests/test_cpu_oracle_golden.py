@@ -176,12 +176,13 @@ def test_c_abi_exports_every_declared_symbol():
     names = _declared(ROOT / "include" / "msgl_hip.h")
     assert len(names) >= 25
     hip, comm = ctypes.CDLL(str(_lib.HIP_SO)), ctypes.CDLL(str(_lib.COMM_SO))
+    gemm = ctypes.CDLL(str(_lib.GEMM_SO))
     for n in names:
-        lib = comm if n.startswith("msgl_comm_") else hip
+        lib = comm if n.startswith("msgl_comm_") else gemm if n.startswith("msgl_gemm_") else hip
         assert hasattr(lib, n), f"{n} declared in include/msgl_hip.h but not exported"
-    _lib.lib(); _lib.comm_lib()
+    _lib.lib(); _lib.comm_lib(); _lib.gemm_lib()
     assert _lib.MISSING_SYMBOLS == []
-    assert set(_lib.HIP_SIGNATURES) | set(_lib.COMM_SIGNATURES) == set(names)
+    assert set(_lib.HIP_SIGNATURES) | set(_lib.COMM_SIGNATURES) | set(_lib.GEMM_SIGNATURES) == set(names)
 
 
 def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
@@ -202,7 +203,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.msgl_rmsnorm(p16, p16, p16, 1e-6, 4, 1, 128, 128, 0, 128, 0, 7, None) == -1  # dtype code
     assert L.msgl_rope_neox_inplace(p16, p16, p16, 0, p16, 4, 2, 2, 96, 512, 512, 0, None) == -1  # head_dim
     assert L.msgl_attn_decode(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 2, 4, 16, 8, 3, 128, 1024, 384, 128,
-                              1024, 0.1, 0, None) == -1  # 8 q heads / 3 kv heads
+                              1024, 0.1, 1, 0, None) == -1  # 8 q heads / 3 kv heads
     assert L.msgl_attn_decode_plan_words(8, 4) == -1
     assert L.msgl_attn_decode_plan_words(8, 64) == 4 + 16 + 128
     assert L.msgl_attn_decode_workspace_bytes(64, 40, 128) == 64 * 40 * 130 * 4

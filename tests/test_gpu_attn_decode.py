@@ -46,7 +46,7 @@ def make_case(g, B, hq, hkv, lens, page_size, dtype=torch.bfloat16, max_seq=None
     return dict(k=k_cache, v=v_cache, table=table, rows=rows, lens=lens, qkv=qkv, hq=hq, hkv=hkv, D=D)
 
 
-def run_decode(ops, dev, case, max_bs=None, capacity=None, min_chunk=64):
+def run_decode(ops, dev, case, max_bs=None, capacity=None, min_chunk=64, slot_run=1):
     B, hq, hkv, D = len(case["lens"]), case["hq"], case["hkv"], case["D"]
     max_bs = max_bs or B
     capacity = capacity or max(4 * max_bs, 1024)
@@ -59,7 +59,7 @@ def run_decode(ops, dev, case, max_bs=None, capacity=None, min_chunk=64):
     rows = torch.tensor(case["rows"], dtype=torch.int32, device=dev)
     ops.attn_decode_plan(plan, seq, B, max_bs, capacity, hkv, min_chunk)
     ops.attn_decode(out, q, case["k"].to(dev), case["v"].to(dev), case["table"].to(dev), rows, seq, plan, ws, B,
-                    max_bs, capacity, 1.0 / math.sqrt(D))
+                    max_bs, capacity, 1.0 / math.sqrt(D), slot_run=slot_run)
     torch.cuda.synchronize()
     return out.cpu(), plan.cpu()
 
@@ -86,10 +86,28 @@ def test_decode_matches_oracle_groups(ops, dev, hq, hkv, page_size):
     g = torch.Generator().manual_seed(hq * 100 + hkv + page_size)
     lens = [1, 2, 15, 16, 17, 63, 64, 65, 200, 777, 1024, 33]
     case = make_case(g, len(lens), hq, hkv, lens, page_size)
-    out, plan = run_decode(ops, dev, case)
     ref = oracle(case)
-    assert torch.isfinite(out.float()).all()
-    torch.testing.assert_close(out.double(), ref, **TOL)
+    # slot_run = 1: per-token table walk; slot_run = page_size: one scalar table read per 16-token tile
+    for slot_run in ([1] if page_size < 16 else [1, page_size]):
+        out, plan = run_decode(ops, dev, case, slot_run=slot_run)
+        assert torch.isfinite(out.float()).all()
+        torch.testing.assert_close(out.double(), ref, **TOL)
+
+
+@pytest.mark.parametrize("page_size,min_chunk", [(16, 16), (64, 64), (256, 64), (256, 256), (48, 32)])
+def test_decode_slot_run_pages(ops, dev, page_size, min_chunk):
+    """Page-aligned allocation (P/scheduler/cache.py:42-53): with slot_run = the largest power of two
+    dividing page_size the kernel reads one table entry per tile; results equal the per-token walk
+    bit for bit (same arithmetic, same order) and match the oracle."""
+    g = torch.Generator().manual_seed(page_size * 7 + min_chunk)
+    lens = [1, 16, 17, 31, 32, 33, 47, 48, 49, 255, 256, 257, 700, 1023, 1024, 1025, 2047, 3000, 5, 64]
+    case = make_case(g, len(lens), 40, 8, lens, page_size)
+    run = page_size & -page_size
+    out_run, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=run)
+    out_tok, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=1)
+    assert torch.isfinite(out_run.float()).all()
+    assert torch.equal(out_run, out_tok)
+    torch.testing.assert_close(out_run.double(), oracle(case), **TOL)
 
 
 @pytest.mark.parametrize("min_chunk", [16, 64, 256])

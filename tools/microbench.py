@@ -67,6 +67,8 @@ def run(args):
     it = 2  # bytes per element
     # ---- decode attention, Qwen3-14B TP1 shape, B=256
     for name, B, hq, hkv, page in [("decode_14b_b256_p256", 256, 40, 8, 256), ("decode_14b_b256_p1", 256, 40, 8, 1),
+                                   ("decode_14b_tp2_b256", 256, 20, 4, 256), ("decode_14b_tp4_b256", 256, 10, 2, 256),
+                                   ("decode_14b_tp8_b256", 256, 5, 1, 256),
                                    ("decode_0.6b_b256", 256, 16, 8, 256), ("decode_32b_tp4_b256", 256, 16, 2, 256),
                                    ("decode_70b_tp8_b256", 256, 8, 1, 256), ("decode_14b_b1", 1, 40, 8, 256),
                                    ("decode_14b_b16", 16, 40, 8, 256)]:
@@ -79,14 +81,21 @@ def run(args):
         seq = torch.tensor(lens, dtype=torch.int32, device=dev)
         out = torch.empty_like(q)
         ops.attn_decode_plan(plan, seq, B, B, cap, hkv)
-        f = lambda: ops.attn_decode(out, q, k, v, table, None, seq, plan, ws, B, B, cap, D ** -0.5)
-        us = time_us(f)
         S = sum(lens)
         bytes_ = S * 2 * hkv * D * it + 2 * B * hq * D * it + S * 4 + 2 * B * 4
         pl = plan[:2].tolist()
-        res[name] = dict(us=us, GBps=bytes_ / us / 1e3, bytes=bytes_, sum_len=S, n_items=pl[0], chunk=pl[1])
+        res[name] = dict(bytes=bytes_, sum_len=S, n_items=pl[0], chunk=pl[1])
+        for run in ([1] if page < 16 else [page, 1]):  # slot_run: scalar table walk vs per-token walk
+            f = lambda: ops.attn_decode(out, q, k, v, table, None, seq, plan, ws, B, B, cap, D ** -0.5, slot_run=run)
+            us = time_us(f)
+            res[name][f"us_run{run}"] = us
+            res[name][f"GBps_run{run}"] = bytes_ / us / 1e3
         print(name, res[name], flush=True)
         del k, v, table, q, ws
+    if args.only == "decode":
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text(json.dumps(res, indent=1))
+        return
     # ---- row ops at decode (T=256) and prefill (T=8192) sizes, hidden 5120
     for T in (256, 8192):
         H = 5120
@@ -132,4 +141,5 @@ def run(args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/microbench.json")
+    ap.add_argument("--only", default="all", choices=["all", "decode"])
     run(ap.parse_args())

@@ -38,7 +38,7 @@ def main():
     for _ in range(3):
         b.copy_(a)
     for _ in range(10):
-        ops.attn_decode(out, q, k, v, table, None, seq, plan, ws, B, B, cap, D ** -0.5)
+        ops.attn_decode(out, q, k, v, table, None, seq, plan, ws, B, B, cap, D ** -0.5, slot_run=256)
     torch.cuda.synchronize()
 
 
