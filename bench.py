@@ -221,7 +221,7 @@ def main() -> None:
     seq = torch.tensor(lens_now, dtype=torch.int32, device=device)
     rows = torch.tensor([s.req.table_idx for s in running], dtype=torch.int32, device=device)
     plan = torch.empty(be._plan_words, dtype=torch.int32, device=device)
-    ops.attn_decode_plan(plan, seq, B, be.max_bs, be.capacity, hkv)
+    ops.attn_decode_plan(plan, seq, B, be.max_bs, be.capacity, hq, hkv)
     q = torch.randn((B, hq, D), device=device, dtype=torch.bfloat16)
     o = torch.empty_like(q)
     k_tok, v_tok = be._kv_tokens(0)

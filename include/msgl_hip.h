@@ -140,18 +140,22 @@ int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, i
  * read in place -- no per-step page-table copy (cf. P/attention/fa.py:92-97).
  * req_rows[b] gives the table row of request b (NULL: row b).
  *
- * Work is split over uniform KV chunks by a device-side plan:
- *   msgl_attn_decode_plan      once per step (seq_lens -> work list)
+ * Work is split by a device-side plan into equal slots of 16-token tiles, one
+ * slot per resident wave of a kv head (a slot = consecutive (request, tile
+ * range) pieces; pieces of one request are merged afterwards):
+ *   msgl_attn_decode_plan      once per step (seq_lens -> slots / pieces)
  *   msgl_attn_decode           once per layer (partial attention + merge)
- * Both are capture-safe; grids are fixed by (max_bs, capacity).
- * min_chunk of the plan must be a multiple of 16 (tiles stay 16-aligned).
+ * Both are capture-safe; grids are fixed by (max_bs, capacity, head counts).
+ * min_chunk: smallest slot in tokens (power of two >= 16).  The plan buffer
+ * must be 16-byte aligned; plan[0] = pieces, [1] = tokens per slot, [3] = slots.
  * ---------------------------------------------------------------------- */
 /* number of int32 words the plan buffer needs */
 int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);
 /* bytes of fp32 workspace for split-KV partials */
 int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim);
 int msgl_attn_decode_plan(int32_t* plan, const int32_t* seq_lens, int batch, int max_bs,
-                          int capacity, int num_kv_heads, int min_chunk, void* stream);
+                          int capacity, int num_q_heads, int num_kv_heads, int min_chunk,
+                          void* stream);
 int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
                      const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
                      const int32_t* seq_lens, const int32_t* plan, void* workspace, int batch,
@@ -227,16 +231,18 @@ const char* msgl_comm_last_error(void);
  * heuristic pick until msgl_gemm_tune has run for it) with the caller's
  * workspace: no allocation, no sync.  msgl_gemm_tune times library solutions
  * on `n_w` rotating weight buffers (max_candidates: 0 = all, n > 1 = first n,
- * -n = heuristic top n, 1 = heuristic pick only), remembers the fastest and
- * SYNCHRONISES (initialisation-time call, not capturable).
+ * -n = heuristic top n, 1 = heuristic pick only; split_k_search != 0 additionally
+ * tries every solution with K split over 2..16 workgroups in the exhaustive modes),
+ * remembers the fastest and SYNCHRONISES (initialisation-time call, not capturable).
  * ---------------------------------------------------------------------- */
 int msgl_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
                  int64_t ldw, int64_t ldo, int dtype, void* workspace, int64_t workspace_bytes,
                  void* stream);
 int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w, int M, int N,
                    int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, void* workspace,
-                   int64_t workspace_bytes, int max_candidates, int iters, float* best_us,
-                   float* default_us, int* best_index, int* n_tried, void* stream);
+                   int64_t workspace_bytes, int max_candidates, int split_k_search, int iters,
+                   float* best_us, float* default_us, int* best_index, int* best_split_k,
+                   int* n_tried, void* stream);
 /* kernel name of the remembered solution into buf; returns its library index (< 0 on error) */
 int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype,
                             char* buf, int buf_len);

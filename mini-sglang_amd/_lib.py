@@ -46,7 +46,7 @@ HIP_SIGNATURES = {
     "msgl_silu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_attn_decode_plan_words": (_l, [_i, _i]),
     "msgl_attn_decode_workspace_bytes": (_l, [_i, _i, _i]),
-    "msgl_attn_decode_plan": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "msgl_attn_decode_plan": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "msgl_attn_decode": (
         _i,
         [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _i, _p],
@@ -75,8 +75,8 @@ GEMM_SIGNATURES = {
     "msgl_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p]),
     "msgl_gemm_tune": (
         _i,
-        [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _l, _l, _l, _i, _p, _l, _i, _i, C.POINTER(_f), C.POINTER(_f),
-         C.POINTER(_i), C.POINTER(_i), _p],
+        [_p, _p, C.POINTER(_p), _i, _i, _i, _i, _l, _l, _l, _i, _p, _l, _i, _i, _i, C.POINTER(_f), C.POINTER(_f),
+         C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _p],
     ),
     "msgl_gemm_solution_name": (_i, [_i, _i, _i, _l, _l, _l, _i, C.c_char_p, _i]),
     "msgl_gemm_last_error": (C.c_char_p, []),

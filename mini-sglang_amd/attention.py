@@ -126,7 +126,7 @@ class HipAttnBackend:
         if decode and not (self._cap_plan is not None and bs in self.capture_bs):
             # eager decode: plan now (device side, no sync); graph batches are planned in prepare_for_replay
             md.plan = torch.empty(self._plan_words, dtype=torch.int32, device=self.device)
-            ops.attn_decode_plan(md.plan, md.seq_lens, bs, self.max_bs, self.capacity, self.kv_heads)
+            ops.attn_decode_plan(md.plan, md.seq_lens, bs, self.max_bs, self.capacity, self.qo_heads, self.kv_heads)
         batch.attn_metadata = md
 
     # ------------------------------------------------------------------ graph hooks
@@ -147,7 +147,7 @@ class HipAttnBackend:
         # dummy requests: length 1, all rows = the dummy request's table row
         self._cap_rows[:bs].fill_(batch.reqs[0].table_idx)
         self._cap_seq[:bs].fill_(1)
-        ops.attn_decode_plan(self._cap_plan, self._cap_seq, bs, self.max_bs, self.capacity, self.kv_heads)
+        ops.attn_decode_plan(self._cap_plan, self._cap_seq, bs, self.max_bs, self.capacity, self.qo_heads, self.kv_heads)
         batch.attn_metadata = HipAttnMetadata(
             cu_seqlens_q=self._cap_cu_q[: bs + 1], seq_lens=self._cap_seq[:bs], req_rows=self._cap_rows[:bs],
             batch=bs, max_seqlen_q=1, max_seqlen_k=int(self.ctx.page_table.shape[1]), plan=self._cap_plan,
@@ -158,4 +158,4 @@ class HipAttnBackend:
         assert isinstance(md, HipAttnMetadata) and bs in self.capture_bs and self._cap_plan is not None
         self._cap_seq[:bs].copy_(md.seq_lens)
         self._cap_rows[:bs].copy_(md.req_rows)
-        ops.attn_decode_plan(self._cap_plan, self._cap_seq, bs, self.max_bs, self.capacity, self.kv_heads)
+        ops.attn_decode_plan(self._cap_plan, self._cap_seq, bs, self.max_bs, self.capacity, self.qo_heads, self.kv_heads)

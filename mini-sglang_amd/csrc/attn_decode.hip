@@ -2,9 +2,12 @@
 // reference's token-granular page table.
 //
 // HBM-bound (intensity = GQA group size, 2..8 flop/B), so the design is a streaming one:
-//   * work unit = (request, uniform KV chunk, kv head), produced by a tiny device-side plan
-//     kernel once per step; the attention grid is fixed (persistent waves stride over the
-//     work list) => legal inside hipGraph replay, balanced for ragged sequence lengths;
+//   * balanced flat split: the 16-token tiles of ALL requests form one line, cut into equal
+//     slots (one per resident wave of a kv head) by a tiny device-side plan kernel once per
+//     step; a slot is a short list of (request, tile range) pieces, so every wave streams the
+//     same number of KV bytes whatever the raggedness of the batch (uniform chunks left the
+//     slowest wave with 1.4x the mean at the bench shape).  The grid is fixed by
+//     (capacity, max_bs) => legal inside hipGraph replay;
 //   * one wave per unit, all G query heads of the GQA group packed in that wave so each
 //     K/V byte is fetched from HBM exactly once;
 //   * a 256-B K (or V) row of one token = one 16-lane DPP row, 16 B per lane => every
@@ -42,55 +45,29 @@ typedef __attribute__((address_space(4))) int CInt;                             
 typedef int I16a __attribute__((ext_vector_type(16), aligned(16)));
 typedef __attribute__((address_space(4))) I16a CI16;
 
-constexpr int kPlanHdr = 4;  // [0] n_items [1] chunk [2] batch [3] reserved
+constexpr int kPlanHdr = 4;  // [0] n_items [1] tokens per slot [2] batch [3] n_slots
 constexpr float kNegBig = -3.0e38f;
 
-// ------------------------------------------------------------------------------
-// plan: seq_lens -> uniform chunks.  One block, 256 threads.
-// ------------------------------------------------------------------------------
-__device__ __forceinline__ int block_sum_256(int x, int* red) {
-  const int tid = threadIdx.x;
-  red[tid] = x;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const int r = red[0];
-  __syncthreads();
-  return r;
+// plan buffer layout (int32 words):
+//   hdr[4] | item_start[max_bs] | n_chunks[max_bs] | tile_start[max_bs] | slot_first[capacity + 1] |
+//   items[4 * capacity] = (request, first tile, end tile, slot)
+__host__ __device__ inline int64_t plan_off_item_start() { return kPlanHdr; }
+__host__ __device__ inline int64_t plan_off_n_chunks(int max_bs) { return kPlanHdr + (int64_t)max_bs; }
+__host__ __device__ inline int64_t plan_off_tile_start(int max_bs) { return kPlanHdr + 2ll * max_bs; }
+__host__ __device__ inline int64_t plan_off_slot_first(int max_bs) { return kPlanHdr + 3ll * max_bs; }
+__host__ __device__ inline int64_t plan_off_items(int max_bs, int capacity) {
+  return ((kPlanHdr + 3ll * max_bs + capacity + 1 + 3) / 4) * 4;  // int4-aligned
 }
 
-__global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan,
-                                                          const int* __restrict__ seq_lens, int batch,
-                                                          int max_bs, int capacity, int target_items,
-                                                          int min_chunk) {
-  __shared__ int red[256];
+// ------------------------------------------------------------------------------
+// plan: seq_lens -> balanced slots.  One block, 256 threads.
+//   nt_b = ceil(S_b / 16) tiles, laid end to end (request-major); slot k owns global tiles
+//   [k q, (k+1) q) with q = max(ceil(NT / target_slots), min_tiles).  A request overlapping m slots
+//   contributes m pieces; pieces are numbered request-major, which also makes the pieces of one slot
+//   consecutive.  Everything is closed-form from two prefix sums.
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ int block_scan_excl_256(int mine, int* red, int* total) {
   const int tid = threadIdx.x;
-  int* item_start = plan + kPlanHdr;
-  int* n_chunks = item_start + max_bs;
-  int* items = n_chunks + max_bs;
-
-  long long local_tok = 0;
-  for (int b = tid; b < batch; b += 256) local_tok += max(seq_lens[b], 0);
-  // totals fit int32: batch * max_seq_len < 2^31 for every supported configuration
-  const int total = block_sum_256((int)local_tok, red);
-
-  int chunk = min_chunk;
-  while (chunk < (1 << 24) && total / chunk > target_items) chunk <<= 1;
-  for (;;) {  // make the work list fit the workspace
-    int local = 0;
-    for (int b = tid; b < batch; b += 256) local += (max(seq_lens[b], 0) + chunk - 1) / chunk;
-    const int n = block_sum_256(local, red);
-    if (n <= capacity || chunk >= (1 << 24)) break;
-    chunk <<= 1;
-  }
-
-  // exclusive scan of per-request chunk counts; thread t owns a contiguous request segment
-  const int per = (batch + 255) / 256;
-  const int b0 = min(tid * per, batch), b1 = min(b0 + per, batch);
-  int mine = 0;
-  for (int b = b0; b < b1; ++b) mine += (max(seq_lens[b], 0) + chunk - 1) / chunk;
   red[tid] = mine;
   __syncthreads();
   if (tid == 0) {
@@ -100,22 +77,80 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan
       red[i] = run;
       run += v;
     }
-    plan[0] = run;
-    plan[1] = chunk;
-    plan[2] = batch;
-    plan[3] = 0;
+    red[256] = run;
   }
   __syncthreads();
-  int run = red[tid];
+  const int r = red[tid];
+  *total = red[256];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan,
+                                                          const int* __restrict__ seq_lens, int batch,
+                                                          int max_bs, int capacity, int target_slots,
+                                                          int min_tiles) {
+  __shared__ int red[257];
+  const int tid = threadIdx.x;
+  int* item_start = plan + plan_off_item_start();
+  int* n_chunks = plan + plan_off_n_chunks(max_bs);
+  int* tile_start = plan + plan_off_tile_start(max_bs);
+  int* slot_first = plan + plan_off_slot_first(max_bs);
+  int* items = plan + plan_off_items(max_bs, capacity);
+
+  // thread t owns a contiguous request segment
+  const int per = (batch + 255) / 256;
+  const int b0 = min(tid * per, batch), b1 = min(b0 + per, batch);
+  int mine = 0;
+  for (int b = b0; b < b1; ++b) mine += (max(seq_lens[b], 0) + 15) >> 4;
+  int NT;  // totals fit int32: batch * max_seq_len / 16 < 2^31 for every supported configuration
+  int run = block_scan_excl_256(mine, red, &NT);
   for (int b = b0; b < b1; ++b) {
-    const int n = (max(seq_lens[b], 0) + chunk - 1) / chunk;
+    tile_start[b] = run;
+    run += (max(seq_lens[b], 0) + 15) >> 4;
+  }
+
+  // items <= n_slots + batch - 1 must fit the workspace
+  int slots = min(target_slots, capacity - batch + 1);
+  if (slots < 1) slots = 1;
+  int q = (NT + slots - 1) / slots;
+  if (q < min_tiles) q = min_tiles;
+  if (q < 1) q = 1;
+  const int n_slots = (NT + q - 1) / q;
+
+  mine = 0;
+  for (int b = b0; b < b1; ++b) {
+    const int nt = (max(seq_lens[b], 0) + 15) >> 4;
+    const int ts = tile_start[b];
+    mine += nt ? ((ts + nt - 1) / q - ts / q + 1) : 0;
+  }
+  int n_items;
+  run = block_scan_excl_256(mine, red, &n_items);
+  for (int b = b0; b < b1; ++b) {
+    const int nt = (max(seq_lens[b], 0) + 15) >> 4;
+    const int ts = tile_start[b];
+    const int k0 = ts / q;
+    const int n = nt ? ((ts + nt - 1) / q - k0 + 1) : 0;
     item_start[b] = run;
     n_chunks[b] = n;
     for (int j = 0; j < n; ++j) {
-      items[2 * (run + j)] = b;
-      items[2 * (run + j) + 1] = j;
+      const int k = k0 + j;
+      const int g0 = max(k * q, ts), g1 = min((k + 1) * q, ts + nt);
+      int* it = items + 4 * (int64_t)(run + j);
+      it[0] = b;
+      it[1] = g0 - ts;
+      it[2] = g1 - ts;
+      it[3] = k;
+      if (g0 == k * q) slot_first[k] = run + j;  // every slot starts with exactly one such piece
     }
     run += n;
+  }
+  if (tid == 0) {
+    plan[0] = n_items;
+    plan[1] = q * 16;
+    plan[2] = batch;
+    plan[3] = n_slots;
+    slot_first[n_slots] = n_items;
   }
 }
 
@@ -134,7 +169,7 @@ struct DecodeParams {
   float* part_o;
   float* part_ml;
   int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
-  int max_bs, hq, hv, group;  // hv = virtual kv heads (hq / G), group = hq / real kv heads
+  int max_bs, capacity, hq, hv, group;  // hv = virtual kv heads (hq / G), group = hq / real kv heads
   int slot_run;               // aligned runs of this many positions map to consecutive slots (1: none)
   float scale_log2;
 };
@@ -152,29 +187,40 @@ __device__ __forceinline__ void pin_tile(Tile& t) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// waves per workgroup: with 2 waves/SIMD (3 <= G <= 5) one 8-wave workgroup fills a CU, and for the
+// common hv = 8 it is exactly the 8 kv heads of ONE slot: they walk the same token rows in step, so a
+// 2-KB token row (8 heads x 256 B) is consumed by one CU within a short window (DRAM page / TLB locality).
+template <int G>
+struct DecodeGeom {
+  static constexpr int kWavesPerBlock = (G >= 3 && G <= 5) ? 8 : 4;
+  static constexpr int kMinWavesPerSimd = G <= 2 ? 3 : G <= 5 ? 2 : 1;
+};
+
 template <typename T, int G, bool kRun>
-__global__ __launch_bounds__(256, (G <= 5 ? 2 : 1)) void attn_decode_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(64 * DecodeGeom<G>::kWavesPerBlock, DecodeGeom<G>::kMinWavesPerSimd) void
+attn_decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
+  constexpr int kWPB = DecodeGeom<G>::kWavesPerBlock;
   const int lane = threadIdx.x & 63;
   const int r = lane >> 4;  // DPP row = token sub-slot
   const int c = lane & 15;  // 16-byte piece of the 256-B head row
-  const int gw = sgpr((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
-  const int nw = (int)gridDim.x * 4;
-  const int n_items = p.plan[0];
-  const int chunk = p.plan[1];
-  const int* item_start = p.plan + kPlanHdr;
-  const int* n_chunks = item_start + p.max_bs;
-  const int* items = n_chunks + p.max_bs;
-  const int total = n_items * p.hv;
+  const int gw = sgpr((int)blockIdx.x * kWPB + (int)(threadIdx.x >> 6));
+  const int slot = gw / p.hv;
+  const int h = gw - slot * p.hv;
+  const int n_slots = p.plan[3];
+  if (slot >= n_slots) return;
+  const int* n_chunks = p.plan + plan_off_n_chunks(p.max_bs);
+  const int* slot_first = p.plan + plan_off_slot_first(p.max_bs);
+  const int4* items = reinterpret_cast<const int4*>(p.plan + plan_off_items(p.max_bs, p.capacity));
+  const int item_begin = sgpr(slot_first[slot]);
+  const int item_end = sgpr(slot_first[slot + 1]);
 
-  for (int wi = gw; wi < total; wi += nw) {
-    const int item = wi / p.hv;
-    const int h = wi - item * p.hv;
-    const int b = sgpr(items[2 * item]);
-    const int j = sgpr(items[2 * item + 1]);
+  for (int item = item_begin; item < item_end; ++item) {
+    const int4 it = items[item];
+    const int b = sgpr(it.x);
     const int S = sgpr(p.seq_lens[b]);
-    const int t0 = j * chunk;
-    const int t1 = min(S, t0 + chunk);
+    const int t0 = sgpr(it.y) * 16;
+    const int t1 = min(S, sgpr(it.z) * 16);
     const int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
     const int* pt = p.page_table + (int64_t)row * p.pt_stride;
     const int hq0 = h * G;
@@ -435,10 +481,10 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
   if (w >= batch * p.hq) return;
   const int b = w / p.hq;
   const int hq = w - b * p.hq;
-  const int* item_start = p.plan + kPlanHdr;
-  const int* n_chunks = item_start + p.max_bs;
+  const int* item_start = p.plan + plan_off_item_start();
+  const int* n_chunks = p.plan + plan_off_n_chunks(p.max_bs);
   const int n = sgpr(n_chunks[b]);
-  if (n <= 1) return;  // single-chunk requests were finished by the attention kernel
+  if (n <= 1) return;  // single-piece requests were finished by the attention kernel
   const int i0 = sgpr(item_start[b]);
   float mx = kNegBig;
   for (int j = 0; j < n; ++j) mx = fmaxf(mx, p.part_ml[((int64_t)(i0 + j) * p.hq + hq) * 2]);
@@ -457,25 +503,51 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
   *op = Elem<T>::pack(acc0 * inv, acc1 * inv);
 }
 
-template <typename T, int G, bool kRun>
-static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
-  static int blocks_per_cu = 0;
-  if (blocks_per_cu == 0) {
+// waves that can be resident at once for heads-per-unit G (drives both the plan and the grid)
+template <typename T, int G>
+static int resident_waves_of() {
+  static int cached = 0;
+  if (cached == 0) {
+    constexpr int kThreads = 64 * DecodeGeom<G>::kWavesPerBlock;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, kRun>, 256, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, false>, kThreads, 0) !=
+            hipSuccess ||
         nb <= 0) {
       (void)hipGetLastError();
-      nb = 2;
+      nb = 1;
     }
-    blocks_per_cu = nb;
+    const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    cached = nb * cus * DecodeGeom<G>::kWavesPerBlock;
   }
-  const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
-  const int64_t max_units = (int64_t)capacity * p.hv;
-  int64_t blocks = (max_units + 3) / 4;
-  const int64_t resident = (int64_t)cus * blocks_per_cu;
-  if (blocks > resident) blocks = resident;
-  if (blocks < 1) blocks = 1;
-  attn_decode_kernel<T, G, kRun><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p);
+  return cached;
+}
+
+static int resident_waves(int G) {
+  switch (G) {
+    case 1: return resident_waves_of<BF16, 1>();
+    case 2: return resident_waves_of<BF16, 2>();
+    case 3: return resident_waves_of<BF16, 3>();
+    case 4: return resident_waves_of<BF16, 4>();
+    case 5: return resident_waves_of<BF16, 5>();
+    case 6: return resident_waves_of<BF16, 6>();
+    case 7: return resident_waves_of<BF16, 7>();
+    default: return resident_waves_of<BF16, 8>();
+  }
+}
+
+// slots the plan may create: one per resident wave of a (virtual) kv head, bounded by the workspace
+static int decode_target_slots(int G, int hv, int capacity, int max_bs) {
+  int slots = resident_waves(G) / hv;
+  if (slots > capacity - max_bs + 1) slots = capacity - max_bs + 1;
+  return slots < 1 ? 1 : slots;
+}
+
+template <typename T, int G, bool kRun>
+static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+  constexpr int kWPB = DecodeGeom<G>::kWavesPerBlock;
+  const int64_t waves = (int64_t)decode_target_slots(G, p.hv, capacity, p.max_bs) * p.hv;
+  const int64_t blocks = (waves + kWPB - 1) / kWPB;
+  attn_decode_kernel<T, G, kRun><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
   const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
   attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
   return MSGL_OK;
@@ -511,23 +583,13 @@ static int heads_per_unit(int group) {
   return 1;
 }
 
-static int decode_oversub() {
-  static int v = 0;
-  if (v == 0) {
-    const char* e = getenv("MSGL_DECODE_OVERSUB");
-    v = e ? atoi(e) : 4;
-    if (v < 1) v = 1;
-  }
-  return v;
-}
-
 }  // namespace msgl
 
 using namespace msgl;
 
 extern "C" int64_t msgl_attn_decode_plan_words(int max_bs, int capacity) {
   if (max_bs < 1 || capacity < max_bs) return MSGL_EINVAL;
-  return (int64_t)kPlanHdr + 2ll * max_bs + 2ll * capacity;
+  return plan_off_items(max_bs, capacity) + 4ll * capacity;
 }
 
 extern "C" int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim) {
@@ -536,20 +598,21 @@ extern "C" int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_head
 }
 
 extern "C" int msgl_attn_decode_plan(int32_t* plan, const int32_t* seq_lens, int batch, int max_bs,
-                                     int capacity, int num_kv_heads, int min_chunk, void* stream) {
+                                     int capacity, int num_q_heads, int num_kv_heads, int min_chunk,
+                                     void* stream) {
   MSGL_REQUIRE(plan && seq_lens, "attn_decode_plan: null pointer");
+  MSGL_REQUIRE((reinterpret_cast<uintptr_t>(plan) & 15u) == 0, "attn_decode_plan: plan must be 16-byte aligned");
   MSGL_REQUIRE(batch >= 1 && batch <= max_bs, "attn_decode_plan: batch %d outside [1, %d]", batch, max_bs);
   MSGL_REQUIRE(capacity >= max_bs, "attn_decode_plan: capacity %d < max_bs %d", capacity, max_bs);
-  MSGL_REQUIRE(num_kv_heads >= 1, "attn_decode_plan: bad head count");
+  MSGL_REQUIRE(num_kv_heads >= 1 && num_q_heads >= num_kv_heads && num_q_heads % num_kv_heads == 0,
+               "attn_decode_plan: %d q heads / %d kv heads", num_q_heads, num_kv_heads);
   if (min_chunk <= 0) min_chunk = 64;
   MSGL_REQUIRE(min_chunk % 16 == 0 && (min_chunk & (min_chunk - 1)) == 0,
                "attn_decode_plan: min_chunk %d must be a power of two >= 16", min_chunk);
-  const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
-  // aim at oversub x (8 waves per CU) work units in total
-  int target = (int)(((int64_t)cus * 8 * decode_oversub()) / num_kv_heads);
-  if (target < 1) target = 1;
+  const int G = heads_per_unit(num_q_heads / num_kv_heads);
+  const int target = decode_target_slots(G, num_q_heads / G, capacity, max_bs);
   decode_plan_kernel<<<dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(
-      plan, seq_lens, batch, max_bs, capacity, target, min_chunk);
+      plan, seq_lens, batch, max_bs, capacity, target, min_chunk / 16);
   MSGL_CHECK_LAUNCH("attn_decode_plan");
   return MSGL_OK;
 }
@@ -574,7 +637,8 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
   MSGL_REQUIRE(q_stride_tok % 8 == 0 && kv_stride_tok % 8 == 0 && kv_stride_head % 8 == 0 &&
                    out_stride_tok % 8 == 0,
                "attn_decode: strides must be multiples of 8 elements");
-  MSGL_REQUIRE(aligned16(out) && aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace),
+  MSGL_REQUIRE(aligned16(out) && aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace) &&
+                   aligned16(plan),
                "attn_decode: pointers must be 16-byte aligned");
   const int group = num_q_heads / num_kv_heads;
   const int G = heads_per_unit(group);
@@ -595,6 +659,7 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
   p.kv_stride_head = kv_stride_head;
   p.out_stride = out_stride_tok;
   p.max_bs = max_bs;
+  p.capacity = capacity;
   p.hq = num_q_heads;
   p.hv = num_q_heads / G;
   p.group = group;

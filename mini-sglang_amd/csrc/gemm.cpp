@@ -81,12 +81,23 @@ struct Problem {
   }
 };
 
+// hipblaslt_ext::Gemm carries data members; this file is compiled against the ROCm headers but may bind
+// (same SONAME) to the libhipblaslt that PyTorch bundles.  The object is therefore constructed by the
+// library's own exported constructor inside an oversized buffer and only ever touched through exported
+// member functions, so a layout difference between the two versions cannot overrun it.
+struct GemmBox {
+  alignas(64) unsigned char raw[2048];
+  hipblaslt_ext::Gemm* get() { return reinterpret_cast<hipblaslt_ext::Gemm*>(raw); }
+};
+
 struct Plan {
   Problem* prob = nullptr;  // owned for process lifetime
   hipblasLtMatmulAlgo_t algo;
   size_t workspace = 0;
   bool tuned = false;
   int algo_index = -1;
+  int split_k = 0;          // 0: the solution's own setting (plain hipblasLtMatmul); > 0: ext Gemm + GemmTuning
+  GemmBox* box = nullptr;   // owned for process lifetime (split_k > 0 only)
 };
 
 std::mutex g_mu;
@@ -138,6 +149,17 @@ int run(hipblasLtHandle_t h, const Plan& pl, void* out, const void* x, const voi
   if (pl.workspace > ws_bytes) {
     set_err("gemm: solution needs %zu workspace bytes, caller gave %zu", pl.workspace, ws_bytes);
     return MSGL_EINVAL;
+  }
+  if (pl.split_k > 0) {
+    // split-K over workgroups (Tensile "GSU"): host-side argument setup, then plain kernel launches
+    hipblaslt_ext::Gemm* g = pl.box->get();
+    GEMM_BLAS(g->setProblem(pl.prob->desc, &alpha, w, pl.prob->a, x, pl.prob->b, &beta, out, pl.prob->d, out,
+                            pl.prob->d));
+    hipblaslt_ext::GemmTuning tuning;
+    tuning.setSplitK((uint16_t)pl.split_k);
+    GEMM_BLAS(g->initialize(pl.algo, tuning, ws, true, s));
+    GEMM_BLAS(g->run(s));
+    return MSGL_OK;
   }
   GEMM_BLAS(hipblasLtMatmul(h, pl.prob->desc, &alpha, w, pl.prob->a, x, pl.prob->b, &beta, out, pl.prob->d, out,
                             pl.prob->d, &pl.algo, ws, ws_bytes, s));
@@ -194,8 +216,8 @@ int msgl_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, i
 
 int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w, int M, int N, int K, int64_t ldx,
                    int64_t ldw, int64_t ldo, int dtype, void* workspace, int64_t workspace_bytes,
-                   int max_candidates, int iters, float* best_us, float* default_us, int* best_index,
-                   int* n_tried, void* stream) {
+                   int max_candidates, int split_k_search, int iters, float* best_us, float* default_us,
+                   int* best_index, int* best_split_k, int* n_tried, void* stream) {
   GEMM_REQUIRE(w_list && n_w >= 1, "gemm_tune: need at least one weight buffer");
   int rc = check_args(out, x, w_list[0], M, N, K, ldx, ldw, ldo, dtype);
   if (rc != MSGL_OK) return rc;
@@ -216,6 +238,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   // max_candidates: 0 = every library solution, n > 1 = the first n of them, -n = the top n of the
   // library's own heuristic ranking (cheap: tens of candidates), 1 = heuristic pick only
   std::vector<hipblasLtMatmulHeuristicResult_t> all;
+  const bool split_search = (max_candidates == 0 || max_candidates > 1) && split_k_search != 0;
   if (max_candidates == 0 || max_candidates > 1) {
     hipblasStatus_t st = hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T,
                                                     HIPBLAS_OP_N, t, t, t, t, HIPBLAS_COMPUTE_32F, all);
@@ -253,21 +276,52 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
     cands.push_back(c);
   }
 
+  // split-K variants of every supported solution (the few-tile shapes N <= 8192 of a decode step leave
+  // most CUs idle otherwise).  Only in the exhaustive modes.
+  if (split_search) {
+    GemmBox* box = new GemmBox();
+    new (box->raw) hipblaslt_ext::Gemm(h, base.prob->desc, &alpha, w_list[0], base.prob->a, x, base.prob->b, &beta,
+                                       out, base.prob->d, out, base.prob->d);
+    const size_t n_plain = cands.size();
+    static const int kSplits[] = {2, 3, 4, 6, 8, 12, 16};
+    for (size_t i = 0; i < n_plain; ++i) {
+      for (int sk : kSplits) {
+        if (K / sk < 512) break;
+        hipblaslt_ext::GemmTuning tuning;
+        tuning.setSplitK((uint16_t)sk);
+        size_t need = 0;
+        hipblasLtMatmulAlgo_t algo = cands[i].algo;
+        if (box->get()->isAlgoSupported(algo, tuning, need) != HIPBLAS_STATUS_SUCCESS) continue;
+        if (need > ws_bytes) continue;
+        Plan c = cands[i];
+        c.algo = algo;
+        c.workspace = need;
+        c.split_k = sk;
+        c.box = box;
+        cands.push_back(c);
+      }
+    }
+  }
+
   hipEvent_t e0, e1;
   GEMM_HIP(hipEventCreate(&e0));
   GEMM_HIP(hipEventCreate(&e1));
+  // Each repetition is bracketed by its own event pair: the split-K path does host-side argument setup
+  // per call, which must not be billed to the kernel (under hipGraph replay it does not exist).
   auto time_us = [&](const Plan& c, int reps, float* us) -> int {
     int r0 = run(h, c, out, x, w_list[0], workspace, ws_bytes, s);  // warm-up (code object load)
     if (r0 != MSGL_OK) return r0;
-    if (hipEventRecord(e0, s) != hipSuccess) return MSGL_ELAUNCH;
+    float total_ms = 0.f;
     for (int i = 0; i < reps; ++i) {
+      if (hipEventRecord(e0, s) != hipSuccess) return MSGL_ELAUNCH;
       r0 = run(h, c, out, x, w_list[(i + 1) % n_w], workspace, ws_bytes, s);
       if (r0 != MSGL_OK) return r0;
+      if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return MSGL_ELAUNCH;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return MSGL_ELAUNCH;
+      total_ms += ms;
     }
-    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return MSGL_ELAUNCH;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return MSGL_ELAUNCH;
-    *us = ms * 1e3f / reps;
+    *us = total_ms * 1e3f / reps;
     return MSGL_OK;
   };
 
@@ -291,7 +345,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   std::sort(ranked.begin(), ranked.end());
   float best = 1e30f, def = -1.f;
   int best_i = 0;
-  const int finals = std::min<int>(8, ranked.size());
+  const int finals = std::min<int>(12, ranked.size());
   for (int r = 0; r < finals; ++r) {
     float us = 0.f;
     if (time_us(cands[ranked[r].second], iters, &us) != MSGL_OK) continue;
@@ -319,6 +373,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   if (best_us) *best_us = best;
   if (default_us) *default_us = def;
   if (best_index) *best_index = chosen.algo_index;
+  if (best_split_k) *best_split_k = chosen.split_k;
   if (n_tried) *n_tried = (int)ranked.size();
   return MSGL_OK;
 }
@@ -334,7 +389,8 @@ int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64
   auto it = g_plans.find(Key{dev, M, N, K, ldx, ldw, ldo, dtype});
   GEMM_REQUIRE(it != g_plans.end(), "gemm_solution_name: shape not planned yet");
   std::string name = hipblaslt_ext::getKernelNameFromAlgo(h, it->second.algo);
-  snprintf(buf, (size_t)buf_len, "%s%s", it->second.tuned ? "[tuned] " : "[heuristic] ", name.c_str());
+  snprintf(buf, (size_t)buf_len, "%s[splitK %d] %s", it->second.tuned ? "[tuned]" : "[heuristic]", it->second.split_k,
+           name.c_str());
   return it->second.algo_index;
 }
 

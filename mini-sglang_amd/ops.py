@@ -208,13 +208,13 @@ def attn_decode_workspace_bytes(capacity: int, num_q_heads: int, head_dim: int) 
 
 
 def attn_decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, batch: int, max_bs: int, capacity: int,
-                     num_kv_heads: int, min_chunk: int = 64) -> None:
+                     num_q_heads: int, num_kv_heads: int, min_chunk: int = 64) -> None:
     _need_cuda(plan, seq_lens)
     assert plan.dtype == torch.int32 and seq_lens.dtype == torch.int32 and seq_lens.is_contiguous()
     assert plan.numel() >= attn_decode_plan_words(max_bs, capacity) and seq_lens.numel() >= batch
     check(
-        lib().msgl_attn_decode_plan(plan.data_ptr(), seq_lens.data_ptr(), batch, max_bs, capacity, num_kv_heads,
-                                    min_chunk, _stream()),
+        lib().msgl_attn_decode_plan(plan.data_ptr(), seq_lens.data_ptr(), batch, max_bs, capacity, num_q_heads,
+                                    num_kv_heads, min_chunk, _stream()),
         "attn_decode_plan",
     )
 
@@ -354,7 +354,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
 
 
 def gemm_tune(x: torch.Tensor, weights, out: Optional[torch.Tensor] = None, max_candidates: int = 0,
-              iters: int = 10) -> dict:
+              iters: int = 10, split_k: bool = True) -> dict:
     """Search the library's solutions for x @ w^T over the same-shaped `weights` (rotated so the
     Infinity Cache cannot hold them) and remember the fastest.  Synchronises; call before capture."""
     import ctypes as C
@@ -367,15 +367,16 @@ def gemm_tune(x: torch.Tensor, weights, out: Optional[torch.Tensor] = None, max_
     ws = gemm_workspace(x.device)
     ptrs = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
     best, default = C.c_float(0), C.c_float(0)
-    idx, tried = C.c_int(-1), C.c_int(0)
+    idx, tried, split = C.c_int(-1), C.c_int(0), C.c_int(0)
     _lib.check_gemm(
         _lib.gemm_lib().msgl_gemm_tune(out.data_ptr(), x.data_ptr(), ptrs, len(weights), M, N, K, x.stride(0),
                                        w0.stride(0), out.stride(0), _dt(x), ws.data_ptr(), ws.numel(),
-                                       max_candidates, iters, C.byref(best), C.byref(default), C.byref(idx),
-                                       C.byref(tried), _stream()),
+                                       max_candidates, int(split_k), iters, C.byref(best), C.byref(default),
+                                       C.byref(idx), C.byref(split), C.byref(tried), _stream()),
         "gemm_tune",
     )
     buf = C.create_string_buffer(512)
     _lib.gemm_lib().msgl_gemm_solution_name(M, N, K, x.stride(0), w0.stride(0), out.stride(0), _dt(x), buf, 512)
-    return dict(M=M, N=N, K=K, best_us=best.value, default_us=default.value, index=idx.value, tried=tried.value,
+    return dict(M=M, N=N, K=K, best_us=best.value, default_us=default.value, index=idx.value, split_k=split.value,
+                tried=tried.value,
                 kernel=buf.value.decode(errors="replace"))

@@ -57,7 +57,7 @@ def run_decode(ops, dev, case, max_bs=None, capacity=None, min_chunk=64, slot_ru
     ws = torch.empty(ops.attn_decode_workspace_bytes(capacity, hq, D), dtype=torch.uint8, device=dev)
     seq = torch.tensor(case["lens"], dtype=torch.int32, device=dev)
     rows = torch.tensor(case["rows"], dtype=torch.int32, device=dev)
-    ops.attn_decode_plan(plan, seq, B, max_bs, capacity, hkv, min_chunk)
+    ops.attn_decode_plan(plan, seq, B, max_bs, capacity, hq, hkv, min_chunk)
     ops.attn_decode(out, q, case["k"].to(dev), case["v"].to(dev), case["table"].to(dev), rows, seq, plan, ws, B,
                     max_bs, capacity, 1.0 / math.sqrt(D), slot_run=slot_run)
     torch.cuda.synchronize()
@@ -110,17 +110,71 @@ def test_decode_slot_run_pages(ops, dev, page_size, min_chunk):
     torch.testing.assert_close(out_run.double(), oracle(case), **TOL)
 
 
-@pytest.mark.parametrize("min_chunk", [16, 64, 256])
+def read_plan(plan, max_bs, capacity, batch):
+    """Decode the device plan (layout: csrc/attn_decode.hip plan_off_*)."""
+    plan = plan.tolist()
+    n_items, slot_tokens, _, n_slots = plan[:4]
+    o_start, o_chunks, o_tiles, o_first = 4, 4 + max_bs, 4 + 2 * max_bs, 4 + 3 * max_bs
+    o_items = (4 + 3 * max_bs + capacity + 1 + 3) // 4 * 4
+    items = [tuple(plan[o_items + 4 * i: o_items + 4 * i + 4]) for i in range(n_items)]
+    return dict(n_items=n_items, slot_tokens=slot_tokens, n_slots=n_slots, items=items,
+                item_start=plan[o_start: o_start + batch], n_chunks=plan[o_chunks: o_chunks + batch],
+                tile_start=plan[o_tiles: o_tiles + batch], slot_first=plan[o_first: o_first + n_slots + 1])
+
+
+def check_plan(pl, lens):
+    """Every tile of every request is covered exactly once, request-major; a slot holds consecutive
+    pieces worth at most slot_tokens / 16 tiles; all slots but the last are full."""
+    q = pl["slot_tokens"] // 16
+    nts = [(n + 15) // 16 for n in lens]
+    assert pl["n_slots"] == (sum(nts) + q - 1) // q
+    cover = [0] * len(lens)
+    load = [0] * pl["n_slots"]
+    for i, (b, t0, t1, k) in enumerate(pl["items"]):
+        assert 0 <= t0 < t1 <= nts[b]
+        assert t0 == cover[b]  # pieces of a request are consecutive and ordered
+        cover[b] = t1
+        load[k] += t1 - t0
+        assert pl["slot_first"][k] <= i < pl["slot_first"][k + 1]
+    assert cover == nts
+    assert all(x == q for x in load[:-1]) and 0 < load[-1] <= q
+    assert pl["slot_first"][-1] == pl["n_items"]
+    for b, n in enumerate(nts):
+        mine = [i for i, it in enumerate(pl["items"]) if it[0] == b]
+        assert len(mine) == pl["n_chunks"][b]
+        assert not mine or (mine[0] == pl["item_start"][b] and mine == list(range(mine[0], mine[0] + len(mine))))
+
+
+@pytest.mark.parametrize("min_chunk", [16, 64, 256, 1024])
 def test_decode_split_kv_chunks(ops, dev, min_chunk):
-    """Long and short requests mixed: multi-chunk merge and single-chunk direct write."""
+    """Long and short requests mixed: multi-piece merge and single-piece direct write; the balanced
+    plan covers every tile exactly once."""
     g = torch.Generator().manual_seed(min_chunk)
     lens = [3000, 5, 1, 2047, 2048, 2049, 300, 17]
     case = make_case(g, len(lens), 40, 8, lens, 1)
     out, plan = run_decode(ops, dev, case, min_chunk=min_chunk)
-    n_items, chunk = int(plan[0]), int(plan[1])
-    assert n_items == sum((n + chunk - 1) // chunk for n in lens)
-    assert chunk >= min_chunk
+    pl = read_plan(plan, len(lens), max(4 * len(lens), 1024), len(lens))
+    assert pl["slot_tokens"] >= min_chunk
+    check_plan(pl, lens)
     torch.testing.assert_close(out.double(), oracle(case), **TOL)
+
+
+def test_decode_plan_balances_the_bench_batch(ops, dev):
+    """256 ragged requests (the offline-bench context distribution): one slot per resident wave of a kv
+    head, all equal (the uniform-chunk plan of round 1 left the slowest wave with 1.4x the mean)."""
+    import random
+
+    rnd = random.Random(0)
+    lens = [rnd.randint(100, 2048) for _ in range(256)]
+    hq, hkv, cap = 40, 8, 4096
+    plan = torch.zeros(ops.attn_decode_plan_words(257, cap), dtype=torch.int32, device=dev)
+    seq = torch.tensor(lens, dtype=torch.int32, device=dev)
+    ops.attn_decode_plan(plan, seq, 256, 257, cap, hq, hkv)
+    torch.cuda.synchronize()
+    pl = read_plan(plan.cpu(), 257, cap, 256)
+    check_plan(pl, lens)
+    assert pl["n_items"] <= pl["n_slots"] + 256
+    assert 64 <= pl["n_slots"] <= 2048
 
 
 def test_decode_plan_respects_capacity(ops, dev):
@@ -129,6 +183,7 @@ def test_decode_plan_respects_capacity(ops, dev):
     case = make_case(g, len(lens), 16, 8, lens, 1)
     out, plan = run_decode(ops, dev, case, max_bs=16, capacity=16, min_chunk=16)
     assert int(plan[0]) <= 16
+    check_plan(read_plan(plan, 16, 16, len(lens)), lens)
     torch.testing.assert_close(out.double(), oracle(case), **TOL)
 
 
@@ -200,12 +255,12 @@ def test_decode_graph_replay(ops, dev):
     ws = torch.empty(ops.attn_decode_workspace_bytes(capacity, hq, D), dtype=torch.uint8, device=dev)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        ops.attn_decode_plan(plan, seq, 8, max_bs, capacity, hkv)
+        ops.attn_decode_plan(plan, seq, 8, max_bs, capacity, hq, hkv)
         ops.attn_decode(out, q, kd, vd, td, rows, seq, plan, ws, 8, max_bs, capacity, D ** -0.5)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
-            ops.attn_decode_plan(plan, seq, 8, max_bs, capacity, hkv)
+            ops.attn_decode_plan(plan, seq, 8, max_bs, capacity, hq, hkv)
             ops.attn_decode(out, q, kd, vd, td, rows, seq, plan, ws, 8, max_bs, capacity, D ** -0.5)
         # replay with the real batch
         seq.copy_(torch.tensor(case["lens"], dtype=torch.int32))

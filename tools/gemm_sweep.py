@@ -64,7 +64,7 @@ def main():
             print(f"bs={bs:4d} {name:8s} N={N:6d} K={K:6d}: heuristic {r['default_us']:8.1f} us "
                   f"({r['default_tflops']:6.0f} TF, {r['default_tbps']:.2f} TB/s) -> best {r['best_us']:8.1f} us "
                   f"({r['best_tflops']:6.0f} TF, {r['best_tbps']:.2f} TB/s) of {r['tried']} in {r['tune_s']:.1f}s "
-                  f"err {err:.3g}/{scale:.3g}\n      {r['kernel'][:160]}", flush=True)
+                  f"err {err:.3g}/{scale:.3g}\n      {r['kernel'][:170]}", flush=True)
             assert err <= 2e-2 * max(scale, 1.0), "tuned solution disagrees with the fp32 reference"
             del ws
         print(f"bs={bs}: GEMM time per decode step  heuristic {tot_def / 1e3:.2f} ms -> tuned {tot_best / 1e3:.2f} ms",

@@ -18,17 +18,25 @@ sys.path.insert(0, str(ROOT))
 from mini_sglang_amd import ops  # noqa: E402
 
 
-def time_us(fn, iters=20, warmup=3):
+def time_us(fn, iters=20, warmup=3, stats=None):
+    """Median of per-launch event timings (a one-off hiccup must not masquerade as kernel time);
+    `stats`, if given, receives min / max / back-to-back average as well."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters):
+    for e0, e1 in evs:
+        e0.record()
         fn()
+        e1.record()
     b.record()
     b.synchronize()
-    return a.elapsed_time(b) * 1e3 / iters
+    ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+    if stats is not None:
+        stats.update(min_us=ts[0], max_us=ts[-1], avg_us=a.elapsed_time(b) * 1e3 / iters)
+    return ts[len(ts) // 2]
 
 
 def bench_lens(n=256, seed=0):
@@ -80,16 +88,18 @@ def run(args):
         ws = torch.empty(ops.attn_decode_workspace_bytes(cap, hq, D), dtype=torch.uint8, device=dev)
         seq = torch.tensor(lens, dtype=torch.int32, device=dev)
         out = torch.empty_like(q)
-        ops.attn_decode_plan(plan, seq, B, B, cap, hkv)
+        ops.attn_decode_plan(plan, seq, B, B, cap, hq, hkv)
         S = sum(lens)
         bytes_ = S * 2 * hkv * D * it + 2 * B * hq * D * it + S * 4 + 2 * B * 4
         pl = plan[:2].tolist()
         res[name] = dict(bytes=bytes_, sum_len=S, n_items=pl[0], chunk=pl[1])
         for run in ([1] if page < 16 else [page, 1]):  # slot_run: scalar table walk vs per-token walk
             f = lambda: ops.attn_decode(out, q, k, v, table, None, seq, plan, ws, B, B, cap, D ** -0.5, slot_run=run)
-            us = time_us(f)
+            st = {}
+            us = time_us(f, stats=st)
             res[name][f"us_run{run}"] = us
             res[name][f"GBps_run{run}"] = bytes_ / us / 1e3
+            res[name][f"minmaxavg_run{run}"] = [round(st["min_us"], 1), round(st["max_us"], 1), round(st["avg_us"], 1)]
         print(name, res[name], flush=True)
         del k, v, table, q, ws
     if args.only == "decode":

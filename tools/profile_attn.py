@@ -29,7 +29,7 @@ def main():
     ws = torch.empty(ops.attn_decode_workspace_bytes(cap, hq, D), dtype=torch.uint8, device=dev)
     seq = torch.tensor(lens, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
-    ops.attn_decode_plan(plan, seq, B, B, cap, hkv)
+    ops.attn_decode_plan(plan, seq, B, B, cap, hq, hkv)
     S = sum(lens)
     print("algorithmic_bytes_per_launch", S * 2 * hkv * D * 2 + 2 * B * hq * D * 2 + S * 4 + 2 * B * 4, flush=True)
     # calibration: a 1 GiB device-to-device copy (known: 1 GiB read + 1 GiB written)
