@@ -108,6 +108,39 @@ def cpu_baseline(cfg, contexts, seconds_budget: float = 25.0):
                        f"to {cfg.num_layers} layers: {est_step * 1e3:.0f} ms/step")
 
 
+def pmc_traffic(attn_bytes: int):
+    """HBM bytes per launch of the decode attention kernel (+merge) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x gfx950 correction + WRITE_SIZE, separate passes; tools/gpu_profile.sh -> profiles/*.json).
+    Counters cannot be read from inside this process, so the figure is taken from the newest profile whose
+    launch shape has exactly this run's algorithmic byte count; otherwise null."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_attn_decode.json")):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        if int(d.get("algorithmic_bytes_per_launch", -1)) == int(attn_bytes):
+            best = (float(d["hbm_bytes_per_launch"]), f"profiles/{f.name}")
+    return best if best else (None, None)
+
+
+def measure_prefill_attention(device, hq: int, hkv: int, budget: int = 16384):
+    """MFMA roofline of the prefill attention kernel on ONE chunk of the bench's own prompts (the first
+    `budget` prompt tokens, no cache hit), one layer: causal flops / HIP-event time."""
+    from tools.microbench import MFMA_PEAK_TFLOPS, prefill_case, prefill_chunk_lens, time_us
+    from mini_sglang_amd import ops
+
+    lens = prefill_chunk_lens(budget, bench_contexts(256))
+    c = prefill_case(lens, lens, hq, hkv, 256, device)
+    us = time_us(lambda: ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"],
+                                          c["tile_cu"], c["B"], c["total_tiles"], 128 ** -0.5,
+                                          tile_order=c["order"]), iters=10, warmup=2)
+    tf = c["flops"] / us / 1e6
+    return {"bound": "mfma", "kernel": "attn_prefill_tr_kernel, one layer, one chunk", "achieved": tf,
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "us_per_launch": us,
+            "flops": c["flops"], "chunk_tokens": c["T"], "requests": c["B"]}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +151,7 @@ def main() -> None:
     ap.add_argument("--page-size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="fill the KV pool with random data instead")
+    ap.add_argument("--no-prefill-roofline", action="store_true", help="skip the prefill-attention MFMA measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,12 +192,21 @@ def main() -> None:
                         cuda_graph_bs=[B] if use_graph else [], page_size=args.page_size,
                         max_seq_len_override=max_seq, comm=comm, memory_ratio=0.9,
                         gemm_tune=os.environ.get("MSGL_GEMM_TUNE", "full"))
+    engine, err = None, None
     try:
         engine = Engine(ecfg, device)
     except Exception as e:  # graph capture with a collective inside may be refused: run eager
         if not use_graph:
             raise
-        print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+        err = f"{type(e).__name__}: {e}"
+    if engine is None:
+        # outside the except block: the failed engine (weights + 0.9 of HBM as KV pool) is only
+        # referenced by the dead traceback; drop it before sizing a second pool
+        import gc
+
+        print(f"[bench] graph capture failed ({err}); falling back to eager", file=sys.stderr)
+        gc.collect()
+        torch.cuda.empty_cache()
         ecfg.cuda_graph_bs = []
         use_graph = False
         engine = Engine(ecfg, device)
@@ -177,6 +220,10 @@ def main() -> None:
 
     # ---------------- prefill (untimed for `value`; yields TTFT) ----------------
     ttft_p50 = None
+    if not args.no_prefill:
+        # one untimed chunk of dummy requests first (library GEMM kernels for the chunk shape, allocator
+        # pools), as the reference bench warms up with one generate() before timing (bench.py:32)
+        runner.warmup_prefill()
     barrier()
     if args.no_prefill:
         engine.kv_cache._kv_buffer.normal_(0.0, 1.0)
@@ -245,6 +292,14 @@ def main() -> None:
     step_bytes = engine.model.streamed_bytes_per_step() + (S + B) * kv_tok + B * mcfg.vocab_size * it
     step_gbps = step_bytes / (ms_per_step * 1e-3) / 1e9
 
+    traffic, traffic_src = pmc_traffic(attn_bytes)
+    prefill_roofline = None
+    if rank == 0 and not args.no_prefill_roofline:
+        try:
+            prefill_roofline = measure_prefill_attention(device, hq, hkv)
+        except Exception as e:  # never lose the headline numbers to the side measurement
+            prefill_roofline = {"error": f"{type(e).__name__}: {e}"}
+
     result = {
         "metric": METRIC, "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
@@ -258,9 +313,10 @@ def main() -> None:
         "ttft_p50_ms": ttft_p50,
         "roofline": {
             "bound": "hbm", "kernel": "attn_decode_kernel (+merge), one layer", "achieved": achieved,
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-            "us_per_launch": attn_us, "algorithmic_bytes": attn_bytes,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "traffic_source": traffic_src, "us_per_launch": attn_us, "algorithmic_bytes": attn_bytes,
         },
+        "prefill_roofline": prefill_roofline,
         "step_roofline": {
             "bound": "hbm", "bytes_per_step_per_rank": step_bytes, "achieved": step_gbps, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS,

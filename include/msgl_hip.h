@@ -46,7 +46,7 @@ extern "C" {
 /* dtype codes for logits */
 #define MSGL_F32 2
 
-#define MSGL_ABI_VERSION 2
+#define MSGL_ABI_VERSION 3
 
 /* Last error message of the calling thread ("" if none). */
 const char* msgl_last_error(void);
@@ -183,7 +183,11 @@ int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void*
                       const int32_t* tile_cu, int batch, int total_tiles, int num_q_heads,
                       int num_kv_heads, int head_dim, int64_t q_stride_tok,
                       int64_t kv_stride_tok, int64_t kv_stride_head, int64_t out_stride_tok,
-                      float sm_scale, int dtype, void* stream);
+                      float sm_scale, int dtype, const int32_t* tile_order, int impl, void* stream);
+/* tile_order (device, [total_tiles], may be NULL = natural order): the order in which q tiles are
+ * scheduled -- the host passes tiles sorted by decreasing key count so the launch tail is made of light
+ * tiles (results do not depend on it).  impl: 0 = default, 1 = first-generation kernel (V transposed
+ * while staging), 2 = ds_read_b64_tr_b16 kernel (double-buffered LDS, XCD-contiguous kv heads). */
 
 /* ------------------------------------------------------------------------
  * Sampling.  Replaces torch.argmax at P/engine/sample.py:73-74 and

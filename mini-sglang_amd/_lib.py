@@ -23,7 +23,7 @@ GEMM_SO = LIB_DIR / "libmsgl_gemm.so"
 BF16, FP16, F32 = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 PREFILL_QTILE = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _u64, _sz = C.c_uint64, C.c_size_t
@@ -53,7 +53,7 @@ HIP_SIGNATURES = {
     ),
     "msgl_attn_prefill": (
         _i,
-        [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p],
+        [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p, _i, _p],
     ),
     "msgl_argmax_rows": (_i, [_p, _p, _l, _l, _l, _i, _p]),
     "msgl_softmax_temperature": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p]),

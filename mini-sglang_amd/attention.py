@@ -16,6 +16,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any, List, Optional
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -32,10 +33,42 @@ class HipAttnMetadata:
     max_seqlen_k: int
     tile_cu: Optional[torch.Tensor] = None  # [B+1] int32 (prefill only)
     total_tiles: int = 0
+    tile_order: Optional[torch.Tensor] = None  # [total_tiles] int32: q tiles, most keys first (prefill only)
     plan: Optional[torch.Tensor] = None     # decode work list (device)
 
     def get_last_indices(self, bs: int) -> torch.Tensor:
         return self.cu_seqlens_q[1: 1 + bs] - 1
+
+
+def prefill_tile_order(seqlens_q: np.ndarray, seqlens_k: np.ndarray, tiles: np.ndarray) -> np.ndarray:
+    """Launch order of the 128-row q tiles of a prefill batch: by decreasing number of keys the tile attends
+    (tile t of request b sees keys [0, min(k_b, k_b - q_b + min((t + 1) * 128, q_b)))), ties in natural order.
+    A scheduling hint only (longest-processing-time first shortens the launch tail); results do not depend on it."""
+    total = int(tiles.sum())
+    req = np.repeat(np.arange(len(tiles)), tiles)
+    first = np.cumsum(tiles) - tiles
+    t_in = np.arange(total) - first[req]
+    q, k = seqlens_q[req], seqlens_k[req]
+    kend = np.minimum(k, k - q + np.minimum((t_in + 1) * _lib.PREFILL_QTILE, q))
+    return np.argsort(-kend, kind="stable").astype(np.int32)
+
+
+def fill_metadata_host(h: np.ndarray, seqlens_q: np.ndarray, seqlens_k: np.ndarray, rows: np.ndarray,
+                       decode: bool) -> None:
+    """Per-batch integers of `prepare_metadata` (fa.py:67-105) in one int32 buffer of 4 B + 2 (+ tiles) words:
+    [seq_lens = device_len (cache_seqlens) | rows = table_idx | cu_seqlens_q [B+1] | tile_cu [B+1] | tile_order].
+    cu_seqlens_q is the reference's in all three regimes (arange for decode, = cu_seqlens_k without a cache
+    hit, own cumsum with one): it is always the exclusive prefix of extend_len."""
+    bs = len(seqlens_q)
+    h[:bs] = seqlens_k
+    h[bs: 2 * bs] = rows
+    h[2 * bs] = 0
+    h[2 * bs + 1: 3 * bs + 1] = np.cumsum(seqlens_q)
+    if not decode:
+        tiles = (seqlens_q + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE
+        h[3 * bs + 1] = 0
+        h[3 * bs + 2: 4 * bs + 2] = np.cumsum(tiles)
+        h[4 * bs + 2:] = prefill_tile_order(seqlens_q, seqlens_k, tiles)
 
 
 class HipAttnBackend:
@@ -91,37 +124,27 @@ class HipAttnBackend:
                             md.batch, self.max_bs, self.capacity, self.scale, slot_run=self.slot_run)
         else:
             ops.attn_prefill(out, q, k_tok, v_tok, table, md.req_rows, md.seq_lens, md.cu_seqlens_q, md.tile_cu,
-                             md.batch, md.total_tiles, self.scale)
+                             md.batch, md.total_tiles, self.scale, tile_order=md.tile_order)
         return out
 
     # ------------------------------------------------------------------ metadata
     def prepare_metadata(self, batch: Any) -> None:
         reqs = batch.padded_reqs
         bs = len(reqs)
-        seqlens_q = [r.extend_len for r in reqs]
-        seqlens_k = [r.device_len for r in reqs]
-        max_q, max_k = max(seqlens_q), max(seqlens_k)
+        seqlens_q = np.fromiter((r.extend_len for r in reqs), dtype=np.int64, count=bs)
+        seqlens_k = np.fromiter((r.device_len for r in reqs), dtype=np.int64, count=bs)
+        rows = np.fromiter((r.table_idx for r in reqs), dtype=np.int64, count=bs)
+        max_q, max_k = int(seqlens_q.max()), int(seqlens_k.max())
         decode = max_q == 1
-        # one pinned buffer: [seq_lens | rows | cu_q | tile_cu]
-        host = torch.empty(4 * bs + 2, dtype=torch.int32, pin_memory=True)
-        host[:bs] = torch.tensor(seqlens_k, dtype=torch.int32)
-        host[bs: 2 * bs] = torch.tensor([r.table_idx for r in reqs], dtype=torch.int32)
-        cu_q = host[2 * bs: 3 * bs + 1]
-        cu_q[0] = 0
-        torch.cumsum(torch.tensor(seqlens_q, dtype=torch.int32), 0, out=cu_q[1:])
-        tile_cu = host[3 * bs + 1: 4 * bs + 2]
-        total_tiles = 0
-        if not decode:
-            tiles = torch.tensor([(n + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE for n in seqlens_q],
-                                 dtype=torch.int32)
-            tile_cu[0] = 0
-            torch.cumsum(tiles, 0, out=tile_cu[1:])
-            total_tiles = int(tile_cu[-1])
+        total_tiles = 0 if decode else int(((seqlens_q + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE).sum())
+        # one pinned buffer, one async H2D copy: [seq_lens | rows | cu_q | tile_cu | tile_order]
+        host = torch.empty(4 * bs + 2 + total_tiles, dtype=torch.int32, pin_memory=True)
+        fill_metadata_host(host.numpy(), seqlens_q, seqlens_k, rows, decode)
         dev = host.to(self.device, non_blocking=True)
         md = HipAttnMetadata(
             cu_seqlens_q=dev[2 * bs: 3 * bs + 1], seq_lens=dev[:bs], req_rows=dev[bs: 2 * bs], batch=bs,
-            max_seqlen_q=max_q, max_seqlen_k=max_k, tile_cu=None if decode else dev[3 * bs + 1:],
-            total_tiles=total_tiles,
+            max_seqlen_q=max_q, max_seqlen_k=max_k, tile_cu=None if decode else dev[3 * bs + 1: 4 * bs + 2],
+            total_tiles=total_tiles, tile_order=None if decode else dev[4 * bs + 2:],
         )
         if decode and not (self._cap_plan is not None and bs in self.capture_bs):
             # eager decode: plan now (device side, no sync); graph batches are planned in prepare_for_replay

@@ -18,6 +18,8 @@
 //           1/l are lane-local.
 // Causal mask is bottom-right aligned (query j of q_len sees keys t <= k_len - q_len + j),
 // applied only on tiles that cross the diagonal; tiles fully above it are skipped.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -54,9 +56,11 @@ struct PrefillParams {
   const int* seq_lens;
   const int* cu_q;
   const int* tile_cu;
+  const int* tile_order;  // optional [total_tiles]: launch order of the q tiles (heaviest first); tr kernel only
   uint16_t* out;
   int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
   int batch, hq, group;
+  int tr_variant;  // bring-up switch (MSGL_TR_VARIANT): 1 = lane j of a tr-read passes row j & 3, chunk j >> 2
   float scale_log2;
 };
 
@@ -249,17 +253,264 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillParams p
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second-generation kernel (impl 2, the default): same math and fragment ownership as above, but
+//   * V is staged ROW-major ([64 keys][256 B], like K: four ds_write_b128 per thread and tile instead of
+//     thirty-two 2-byte transposing stores) and the V^T MFMA fragments come out of LDS through the gfx950
+//     transposing read ds_read_b64_tr_b16: a 16-lane group reads one [4 keys][16 d] block (lane j passes the
+//     address of row j>>2, columns 4(j&3)..+3) and lane j receives column j of it = its 4 consecutive keys.
+//     64-B XOR swizzle on the key's low two bits => the 32 lanes of a read hit 64 distinct banks;
+//   * K/V tiles are double-buffered in LDS (64 KB per workgroup): ONE barrier per 64-key tile; loads for tile
+//     t+1 are issued before tile t's MFMAs and written to LDS after them; page-table slots run one more
+//     tile ahead so the gather never waits for its own indices;
+//   * <= 256 registers: two workgroups (8 waves) per CU, so one workgroup's softmax overlaps the other's MFMAs;
+//   * 1-D grid remapped so that each XCD owns a contiguous range of (kv head, q tile, q head of the group):
+//     the G query heads that share a K/V tile run back to back on ONE XCD's L2 (at Hkv = 8: kv head == XCD);
+//     q tiles are taken in the caller's order (heaviest first) so the tail is made of light tiles;
+//   * the O rescale is skipped (exactly) on tiles where no row's running max moved.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) char lds_char;
+
+__device__ __forceinline__ int v_off(int key, int byte_in_row) { return key * 256 + (byte_in_row ^ ((key & 3) << 6)); }
+
+__device__ __forceinline__ uint2 tr_read_b64(const char* lds_ptr) {
+  const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_char*)lds_ptr);
+  return __builtin_bit_cast(uint2, r);
+}
+
+constexpr int kTileBytes = kKTile * kD * 2;  // 16 KB: one K (or V) tile image
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillParams p, int total_tiles) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * kTileBytes];  // [buf][K | V]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int hi = lane >> 5;
+
+  // ---- block -> (kv head, q tile, head of the group): XCD-contiguous virtual index ------------------
+  const int n_per = (int)(gridDim.x >> 3);
+  const int vidx = (int)(blockIdx.x & 7) * n_per + (int)(blockIdx.x >> 3);
+  if (vidx >= total_tiles * p.hq) return;
+  const int per_kv = total_tiles * p.group;
+  const int kvh = vidx / per_kv;
+  const int rem = vidx - kvh * per_kv;
+  const int ti = rem / p.group;
+  const int hq = kvh * p.group + (rem - ti * p.group);
+  const int tile = p.tile_order ? p.tile_order[ti] : ti;
+
+  int lo = 0, hi_b = p.batch;  // find b with tile_cu[b] <= tile < tile_cu[b+1]
+  while (hi_b - lo > 1) {
+    const int mid = (lo + hi_b) >> 1;
+    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
+  }
+  const int b = lo;
+  const int q_begin = p.cu_q[b];
+  const int q_len = p.cu_q[b + 1] - q_begin;
+  const int k_len = p.seq_lens[b];
+  const int q0 = (tile - p.tile_cu[b]) * kQTile;
+  const int row = p.req_rows ? p.req_rows[b] : b;
+  const int* pt = p.page_table + (int64_t)row * p.pt_stride;
+  const int diag = k_len - q_len;
+  const int kend = min(k_len, diag + min(q0 + kQTile, q_len));
+  const int ntiles = (kend + kKTile - 1) / kKTile;
+
+  // ---- Q fragments ------------------------------------------------------------------------------
+  const int my_q = q0 + wave * 32 + (lane & 31);
+  const bool q_valid = my_q < q_len;
+  const int64_t q_tok = q_begin + (q_valid ? my_q : q_len - 1);
+  U4 qf[8];
+  {
+    const uint16_t* qp = p.q + q_tok * p.q_stride + (int64_t)hq * kD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = ldg16(qp + ks * 16);
+  }
+  const int my_qpos = diag + my_q;
+  const int wave_min_qpos = diag + q0 + wave * 32;
+
+  f32x16 o[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+  float m_run = kNegBigP, l_run = 0.f;
+
+  // ---- staging: thread owns 16-byte pieces c = tid + 256 i (key = c >> 4, piece = c & 15) -----------
+  const int st_key = tid >> 4, st_piece = tid & 15;  // key of piece i = st_key + 16 i
+  const int64_t head_off = (int64_t)kvh * p.kv_stride_head + st_piece * 8;
+  int sl[4];
+  U4 kreg[4], vreg[4];
+  auto load_slots = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sl[i] = pt[min(kt * kKTile + st_key + 16 * i, k_len - 1)];  // never past the sequence
+  };
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t off = (int64_t)sl[i] * p.kv_stride_tok + head_off;
+      kreg[i] = ldg16(p.k + off);
+      vreg[i] = ldg16(p.v + off);
+    }
+  };
+  auto write_lds = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = st_key + 16 * i;
+      *reinterpret_cast<U4*>(buf + k_off(key, st_piece * 16)) = kreg[i];
+      *reinterpret_cast<U4*>(buf + kTileBytes + v_off(key, st_piece * 16)) = vreg[i];
+    }
+  };
+  // V^T fragment addressing: lane = 16 g4 + j; the lane's share of a [4 keys][16 d] block is row j >> 2,
+  // columns 16 (g4 & 1) + 4 (j & 3) .. +3 of d block nb; the swizzle term depends on the lane's row only
+  int voff[4];
+  {
+    const int j = lane & 15;
+    const int r4 = p.tr_variant ? (j & 3) : (j >> 2);
+    const int ch = p.tr_variant ? (j >> 2) : (j & 3);
+    const int w = (16 * ((lane >> 4) & 1) + 4 * ch) * 2;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) voff[nb] = kTileBytes + hi * 1024 + r4 * 256 + (((nb ^ r4) & 3) << 6) + w;
+  }
+
+  if (ntiles > 0) {
+    load_slots(0);
+    issue_loads();
+    if (ntiles > 1) load_slots(1);
+  }
+  for (int kt = 0; kt < ntiles; ++kt) {
+    char* buf = lds + (kt & 1) * (2 * kTileBytes);
+    write_lds(buf);  // tile kt (its loads were issued one tile ago); the buffer was last read at tile kt-2
+    if (kt + 1 < ntiles) {
+      issue_loads();  // tile kt+1: in flight during this tile's MFMAs
+      if (kt + 2 < ntiles) load_slots(kt + 2);
+    }
+    __syncthreads();
+
+    const int key0 = kt * kKTile;
+    if (key0 > diag + q0 + wave * 32 + 31) continue;  // whole tile above this wave's diagonal
+
+    // ---- S^T = K . Q^T -----------------------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const int key = kb * 32 + (lane & 31);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const U4 a = *reinterpret_cast<const U4*>(buf + k_off(key, ks * 32 + hi * 16));
+        s[kb] = mfma32<T>(a, qf[ks], s[kb]);
+      }
+    }
+    // ---- scale, mask, online softmax (lane-local row) ------------------------------------
+    const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
+    float tmax = kNegBigP;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float x = s[kb][r] * p.scale_log2;
+        if (need_mask) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key > my_qpos) x = -INFINITY;
+        }
+        s[kb][r] = x;
+        tmax = fmaxf(tmax, x);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        s[kb][r] = e;
+        rsum += e;
+      }
+    }
+    rsum += __shfl_xor(rsum, 32, 64);
+    l_run = fmaf(l_run, alpha, rsum);
+    if (!__all(m_new == m_run)) {  // alpha == 1 on every row otherwise: the rescale would be the identity
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+    }
+    m_run = m_new;
+
+    // ---- O^T += V^T . P^T ------------------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        U4 pf;
+        pf.x = Elem<T>::pack(s[kb][8 * half + 0], s[kb][8 * half + 1]);
+        pf.y = Elem<T>::pack(s[kb][8 * half + 2], s[kb][8 * half + 3]);
+        pf.z = Elem<T>::pack(s[kb][8 * half + 4], s[kb][8 * half + 5]);
+        pf.w = Elem<T>::pack(s[kb][8 * half + 6], s[kb][8 * half + 7]);
+        // lane's keys: 4-key unit u1 = kb 8 + half 4 + hi (k slots 0..3) and unit u1 + 2 (k slots 4..7);
+        // unit u = rows 4u..4u+3 = 1 KB of the image (hi is folded into voff)
+        constexpr int kUnitBytes = 4 * 256;
+        const int ub = (kb * 8 + half * 4) * kUnitBytes;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const uint2 v1 = tr_read_b64(buf + voff[nb] + ub);
+          const uint2 v2 = tr_read_b64(buf + voff[nb] + ub + 2 * kUnitBytes);
+          U4 vf;
+          vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
+          o[nb] = mfma32<T>(vf, pf, o[nb]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: O[q row][d] = O^T / l ---------------------------------------------------------
+  if (q_valid) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = nb * 32 + 8 * rg + 4 * hi;
+        uint2 w;
+        w.x = Elem<T>::pack(o[nb][4 * rg + 0] * inv, o[nb][4 * rg + 1] * inv);
+        w.y = Elem<T>::pack(o[nb][4 * rg + 2] * inv, o[nb][4 * rg + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = w;
+      }
+    }
+  }
+}
+
 }  // namespace msgl
 
 using namespace msgl;
+
+// MSGL_PREFILL_IMPL=1|2 overrides the default kernel generation (A/B runs); read once.
+static int default_prefill_impl() {
+  static int cached = 0;
+  if (cached == 0) {
+    const char* e = getenv("MSGL_PREFILL_IMPL");
+    cached = (e && e[0] == '1') ? 1 : 2;
+  }
+  return cached;
+}
 
 extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
                                  const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
                                  const int32_t* seq_lens, const int32_t* cu_seqlens_q, const int32_t* tile_cu,
                                  int batch, int total_tiles, int num_q_heads, int num_kv_heads, int head_dim,
                                  int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
-                                 int64_t out_stride_tok, float sm_scale, int dtype, void* stream) {
+                                 int64_t out_stride_tok, float sm_scale, int dtype, const int32_t* tile_order,
+                                 int impl, void* stream) {
   MSGL_REQUIRE(batch >= 0 && total_tiles >= 0, "attn_prefill: negative sizes");
+  MSGL_REQUIRE(impl >= 0 && impl <= 2, "attn_prefill: impl %d (0 default, 1 register-transposed V, 2 tr-read)", impl);
   if (batch == 0 || total_tiles == 0) return MSGL_OK;
   MSGL_REQUIRE(out && q && k_cache && v_cache && page_table && seq_lens && cu_seqlens_q && tile_cu,
                "attn_prefill: null pointer");
@@ -281,6 +532,7 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
   p.seq_lens = seq_lens;
   p.cu_q = cu_seqlens_q;
   p.tile_cu = tile_cu;
+  p.tile_order = tile_order;
   p.out = (uint16_t*)out;
   p.pt_stride = pt_stride;
   p.q_stride = q_stride_tok;
@@ -290,14 +542,27 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
   p.batch = batch;
   p.hq = num_q_heads;
   p.group = num_q_heads / num_kv_heads;
+  {
+    static const char* e = getenv("MSGL_TR_VARIANT");
+    p.tr_variant = (e && e[0] == '1') ? 1 : 0;
+  }
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)total_tiles, (unsigned)num_q_heads), block(256);
-  if (dtype == MSGL_BF16) attn_prefill_kernel<BF16><<<grid, block, 0, s>>>(p);
-  else if (dtype == MSGL_FP16) attn_prefill_kernel<FP16><<<grid, block, 0, s>>>(p);
-  else {
+  if (dtype != MSGL_BF16 && dtype != MSGL_FP16) {
     set_error("attn_prefill: unsupported dtype code %d", dtype);
     return MSGL_EINVAL;
+  }
+  if (impl == 0) impl = default_prefill_impl();
+  if (impl == 1) {  // first-generation kernel: 2-D grid in natural order (tile_order unused)
+    const dim3 grid((unsigned)total_tiles, (unsigned)num_q_heads), block(256);
+    if (dtype == MSGL_BF16) attn_prefill_kernel<BF16><<<grid, block, 0, s>>>(p);
+    else attn_prefill_kernel<FP16><<<grid, block, 0, s>>>(p);
+  } else {
+    const int64_t total = (int64_t)total_tiles * num_q_heads;
+    MSGL_REQUIRE(total < (1ll << 30), "attn_prefill: %lld workgroups", (long long)total);
+    const unsigned blocks = (unsigned)((total + 7) / 8) * 8;  // 8 XCDs x n_per
+    if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+    else attn_prefill_tr_kernel<FP16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
   }
   MSGL_CHECK_LAUNCH("attn_prefill");
   return MSGL_OK;

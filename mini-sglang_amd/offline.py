@@ -122,6 +122,31 @@ class OfflineRunner:
         self.token_pool[row, : len(ids)] = ids.pin_memory().to(self.device, non_blocking=True)
         return RequestState(req=req, prompt_len=len(ids), max_tokens=out_len, t_submit=time.perf_counter())
 
+    def warmup_prefill(self, tokens: Optional[int] = None) -> None:
+        """One untimed prefill forward of `tokens` (default: the chunk budget) new tokens of dummy requests.
+        They all sit on the engine's dummy table row, whose every entry is the dummy page (P/engine/engine.py:
+        89-98), so K/V land there and no request state is touched.  Purpose: first-use costs of the chunk
+        shape (library GEMM kernel load + heuristic, allocator growth) stay out of TTFT, like the one-prompt
+        warm-up generate() of the reference's benchmark (benchmark/offline/bench.py:32)."""
+        eng = self.engine
+        tokens = tokens or self.max_extend_tokens
+        per = max(1, min(eng.max_seq_len - 1, tokens))
+        lens = [per] * (tokens // per) + ([tokens % per] if tokens % per else [])
+        row = eng.dummy_req.table_idx
+        reqs = [Req(input_ids=torch.zeros(n, dtype=torch.int32), table_idx=row, cached_len=0, output_len=1, uid=-1,
+                    sampling_params=SamplingParams()) for n in lens]
+        batch = Batch(reqs=reqs, phase="prefill")  # type: ignore[arg-type]
+        batch.padded_reqs = reqs
+        pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
+        batch.positions = torch.from_numpy(pos).pin_memory().to(self.device, non_blocking=True)
+        batch.out_loc = torch.full((len(pos),), eng.num_pages * self.page_size, dtype=torch.int32, device=self.device)
+        batch.input_ids = torch.zeros(len(pos), dtype=torch.int32, device=self.device)
+        eng.attn_backend.prepare_metadata(batch)
+        with eng.ctx.forward_batch(batch):
+            logits = eng.model.forward(eng.ctx, batch)
+        eng.sampler.sample(logits, eng.sampler.prepare(batch))
+        del logits
+
     def prefill(self, states: List[RequestState]) -> List:
         """Chunked prefill of all requests under the token budget (P/scheduler/prefill.py:65-90:
         a request cut by the budget continues in the next forward with cached_len advanced)."""

@@ -247,8 +247,13 @@ def attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cac
 def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                  page_table: torch.Tensor, req_rows: Optional[torch.Tensor], seq_lens: torch.Tensor,
                  cu_seqlens_q: torch.Tensor, tile_cu: torch.Tensor, batch: int, total_tiles: int,
-                 sm_scale: float) -> None:
+                 sm_scale: float, tile_order: Optional[torch.Tensor] = None, impl: int = 0) -> None:
+    """tile_order: optional int32 [total_tiles] schedule of the q tiles (heaviest first); impl: 0 default,
+    1 first-generation kernel, 2 tr-read kernel (include/msgl_hip.h)."""
     _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, cu_seqlens_q, tile_cu)
+    if tile_order is not None:
+        _need_cuda(tile_order)
+        assert tile_order.dtype == torch.int32 and tile_order.is_contiguous() and tile_order.numel() == total_tiles
     hq, d = q.shape[1], q.shape[2]
     hkv = k_cache.shape[1]
     assert q.stride(2) == 1 and q.stride(1) == d and out.stride(2) == 1 and out.stride(1) == d
@@ -259,7 +264,8 @@ def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_ca
             out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), page_table.data_ptr(),
             page_table.stride(0), req_rows.data_ptr() if req_rows is not None else None, seq_lens.data_ptr(),
             cu_seqlens_q.data_ptr(), tile_cu.data_ptr(), batch, total_tiles, hq, hkv, d, q.stride(0),
-            k_cache.stride(0), k_cache.stride(1), out.stride(0), float(sm_scale), _dt(q), _stream(),
+            k_cache.stride(0), k_cache.stride(1), out.stride(0), float(sm_scale), _dt(q),
+            tile_order.data_ptr() if tile_order is not None else None, int(impl), _stream(),
         ),
         "attn_prefill",
     )

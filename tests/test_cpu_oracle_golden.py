@@ -61,6 +61,53 @@ def test_fa_metadata_oracle_matches_reference(golden_dir):
         assert md["max_seqlen_k"] == c["max_seqlen_k"] and md["max_seqlen_q"] == c["max_seqlen_q"]
 
 
+def test_product_metadata_host_buffer_matches_reference(golden_dir):
+    """The product's host-side metadata assembly (attention.fill_metadata_host, no device needed) against the
+    reference's FlashAttentionBackend.prepare_metadata outputs: cache_seqlens, cu_seqlens_q, last indices."""
+    import numpy as np
+
+    from mini_sglang_amd import _lib
+    from mini_sglang_amd.attention import fill_metadata_host, prefill_tile_order
+
+    gold = torch.load(golden_dir / "fa_metadata.pt")
+    for name, c in gold.items():
+        specs = c["specs"]  # (table_idx, cached_len, device_len)
+        rows = np.array([s[0] for s in specs], dtype=np.int64)
+        q = np.array([s[2] - s[1] for s in specs], dtype=np.int64)
+        k = np.array([s[2] for s in specs], dtype=np.int64)
+        bs = len(specs)
+        decode = int(q.max()) == 1
+        tiles = (q + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE
+        total = 0 if decode else int(tiles.sum())
+        h = np.full(4 * bs + 2 + total, -7, dtype=np.int32)
+        fill_metadata_host(h, q, k, rows, decode)
+        assert np.array_equal(h[:bs], c["cache_seqlens"].numpy()), name
+        assert np.array_equal(h[bs: 2 * bs], rows), name
+        assert np.array_equal(h[2 * bs: 3 * bs + 1], c["cu_seqlens_q"].numpy()), name
+        assert np.array_equal(h[2 * bs + 1: 3 * bs + 1] - 1, c["last_indices"].numpy()), name
+        if not decode:
+            assert h[3 * bs + 1] == 0 and np.array_equal(np.diff(h[3 * bs + 1: 4 * bs + 2]), tiles), name
+            order = h[4 * bs + 2:]
+            assert sorted(order.tolist()) == list(range(total)), name  # a permutation of the q tiles
+
+
+def test_prefill_tile_order_is_heaviest_first():
+    import numpy as np
+
+    from mini_sglang_amd.attention import prefill_tile_order
+
+    q = np.array([300, 1, 128, 129, 700], dtype=np.int64)
+    k = np.array([300, 900, 128, 1000, 700], dtype=np.int64)
+    tiles = (q + 127) // 128
+    order = prefill_tile_order(q, k, tiles)
+    req = np.repeat(np.arange(5), tiles)
+    t_in = np.arange(tiles.sum()) - (np.cumsum(tiles) - tiles)[req]
+    kend = np.minimum(k[req], k[req] - q[req] + np.minimum((t_in + 1) * 128, q[req]))
+    assert sorted(order.tolist()) == list(range(int(tiles.sum())))
+    assert (np.diff(kend[order]) <= 0).all()
+    assert kend[order[0]] == 1000 and kend.min() == kend[order[-1]]
+
+
 def test_in_place_page_table_walk_equals_reference_page_table(golden_dir):
     """The kernels read ctx.page_table[table_idx, t] (token slots) directly.  That must address
     the same KV rows as the reference's per-step table: slot(t) == page_table_new[b, t // page] * page

@@ -53,7 +53,17 @@ def build(g, specs, hq, hkv, page_size, dtype=torch.bfloat16):
                 hkv=hkv)
 
 
-def run(ops, dev, c):
+@pytest.fixture(params=[2, 1], ids=["tr_read", "gen1"])
+def impl(request):
+    """Both kernel generations (include/msgl_hip.h: impl 2 = ds_read_b64_tr_b16 kernel, the default; 1 = first one)."""
+    return request.param
+
+
+def run(ops, dev, c, impl=0, order="heavy"):
+    import numpy as np
+
+    from mini_sglang_amd.attention import prefill_tile_order
+
     D, hq = 128, c["hq"]
     qkv = c["qkv"].to(dev)
     T = qkv.shape[0]
@@ -62,10 +72,17 @@ def run(ops, dev, c):
     cu_q = torch.tensor([0] + c["q_lens"], dtype=torch.int32).cumsum(0).to(torch.int32)
     tiles = [(n + 127) // 128 for n in c["q_lens"]]
     tile_cu = torch.tensor([0] + tiles, dtype=torch.int32).cumsum(0).to(torch.int32)
+    tile_order = None
+    if order == "heavy":
+        tile_order = torch.from_numpy(prefill_tile_order(np.array(c["q_lens"], dtype=np.int64),
+                                                         np.array(c["k_lens"], dtype=np.int64),
+                                                         np.array(tiles, dtype=np.int64))).to(dev)
+    elif order == "reversed":
+        tile_order = torch.arange(int(tile_cu[-1]) - 1, -1, -1, dtype=torch.int32, device=dev)
     ops.attn_prefill(out, q, c["k"].to(dev), c["v"].to(dev), c["table"].to(dev),
                      torch.tensor(c["rows"], dtype=torch.int32, device=dev),
                      torch.tensor(c["k_lens"], dtype=torch.int32, device=dev), cu_q.to(dev), tile_cu.to(dev),
-                     len(c["q_lens"]), int(tile_cu[-1]), D ** -0.5)
+                     len(c["q_lens"]), int(tile_cu[-1]), D ** -0.5, tile_order=tile_order, impl=impl)
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -80,40 +97,58 @@ def oracle(c):
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (40, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("page_size", [1, 16])
-def test_prefill_no_cache_hit(ops, dev, hq, hkv, page_size):
+def test_prefill_no_cache_hit(ops, dev, impl, hq, hkv, page_size):
     g = torch.Generator().manual_seed(hq + page_size)
     specs = [(0, n) for n in (1, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 300, 517)]
     c = build(g, specs, hq, hkv, page_size)
-    out = run(ops, dev, c)
+    out = run(ops, dev, c, impl)
     assert torch.isfinite(out.float()).all()
     torch.testing.assert_close(out.double(), oracle(c), **TOL)
 
 
-def test_prefill_partial_hit_and_chunked(ops, dev):
+def test_prefill_partial_hit_and_chunked(ops, dev, impl):
     """q_len < k_len: radix prefix hits (page-aligned cached_len) and chunked-prefill continuation."""
     g = torch.Generator().manual_seed(1)
     specs = [(16, 40), (64, 65), (128, 400), (1000, 1001), (512, 1024), (0, 7), (256, 257 + 128), (48, 49)]
     c = build(g, specs, 40, 8, 16)
-    out = run(ops, dev, c)
+    out = run(ops, dev, c, impl)
     torch.testing.assert_close(out.double(), oracle(c), **TOL)
 
 
-def test_prefill_long(ops, dev):
+def test_prefill_tile_order_does_not_change_results(ops, dev):
+    """tile_order is a scheduling hint: natural, heaviest-first and reversed orders are bit-identical."""
+    g = torch.Generator().manual_seed(11)
+    specs = [(0, 300), (128, 400), (0, 1), (512, 1024), (0, 129)]
+    c = build(g, specs, 10, 2, 16)
+    a = run(ops, dev, c, 2, order="heavy")
+    assert torch.equal(a, run(ops, dev, c, 2, order=None))
+    assert torch.equal(a, run(ops, dev, c, 2, order="reversed"))
+    torch.testing.assert_close(a.double(), oracle(c), **TOL)
+
+
+def test_prefill_generations_agree(ops, dev):
+    """Same fragment ownership and accumulation order in both kernels => identical bits."""
+    g = torch.Generator().manual_seed(12)
+    c = build(g, [(0, 517), (64, 200), (1000, 1100)], 16, 8, 1)
+    assert torch.equal(run(ops, dev, c, 1), run(ops, dev, c, 2))
+
+
+def test_prefill_long(ops, dev, impl):
     g = torch.Generator().manual_seed(2)
     specs = [(0, 2048), (1024, 3000)]
     c = build(g, specs, 16, 8, 1)
-    out = run(ops, dev, c)
+    out = run(ops, dev, c, impl)
     torch.testing.assert_close(out.double(), oracle(c), **TOL)
 
 
-def test_prefill_fp16(ops, dev):
+def test_prefill_fp16(ops, dev, impl):
     g = torch.Generator().manual_seed(3)
     c = build(g, [(0, 200), (32, 90)], 16, 8, 1, dtype=torch.float16)
-    out = run(ops, dev, c)
+    out = run(ops, dev, c, impl)
     torch.testing.assert_close(out.double(), oracle(c), atol=2e-3, rtol=2 ** -8)
 
 
-def test_prefill_transpose_detecting(ops, dev):
+def test_prefill_transpose_detecting(ops, dev, impl):
     """Asymmetric structured inputs (guide rule 16): V[key, d] = key + d/1000 with uniform
     attention => O[q, d] = mean_key(key) + d/1000; a swapped row/col layout cannot pass."""
     g = torch.Generator().manual_seed(4)
@@ -125,7 +160,7 @@ def test_prefill_transpose_detecting(ops, dev):
     dd = torch.arange(D, dtype=torch.float32).view(1, 1, D) / 64.0
     hh = torch.arange(8, dtype=torch.float32).view(1, 8, 1)
     c["v"][slots] = (keys + dd + hh).to(torch.bfloat16)
-    out = run(ops, dev, c)
+    out = run(ops, dev, c, impl)
     torch.testing.assert_close(out.double(), oracle(c), **TOL)
 
 

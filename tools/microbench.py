@@ -69,10 +69,93 @@ def decode_case(B, hq, hkv, lens, page_size, dev, dtype=torch.bfloat16, D=128):
     return k, v, table.to(dev), q
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16
+
+
+def prefill_case(q_lens, k_lens, hq, hkv, page_size, dev, dtype=torch.bfloat16, D=128):
+    """A prefill batch in a shuffled paged pool: returns the ops.attn_prefill argument tuple + causal flops."""
+    import numpy as np
+
+    from mini_sglang_amd.attention import prefill_tile_order
+
+    B = len(q_lens)
+    max_seq = (max(k_lens) + 31) // 32 * 32
+    pages = [-(-n // page_size) for n in k_lens]
+    n_pages = sum(pages) + 1
+    k = torch.randn((n_pages * page_size, hkv, D), device=dev, dtype=dtype)
+    v = torch.randn((n_pages * page_size, hkv, D), device=dev, dtype=dtype)
+    perm = torch.randperm(n_pages - 1)
+    table = torch.zeros((B, max_seq), dtype=torch.int32)
+    pp = 0
+    for b in range(B):
+        pg = perm[pp: pp + pages[b]].to(torch.int32) * page_size
+        pp += pages[b]
+        tok = (pg.unsqueeze(1) + torch.arange(page_size, dtype=torch.int32)).flatten()
+        table[b, : k_lens[b]] = tok[: k_lens[b]]
+    T = sum(q_lens)
+    q = torch.randn((T, hq, D), device=dev, dtype=dtype)
+    out = torch.empty_like(q)
+    cu_q = torch.tensor([0] + list(q_lens), dtype=torch.int32).cumsum(0).to(torch.int32).to(dev)
+    tiles = np.array([(n + 127) // 128 for n in q_lens], dtype=np.int64)
+    tile_cu = torch.tensor([0] + tiles.tolist(), dtype=torch.int32).cumsum(0).to(torch.int32).to(dev)
+    order = torch.from_numpy(prefill_tile_order(np.array(q_lens, dtype=np.int64), np.array(k_lens, dtype=np.int64),
+                                                tiles)).to(dev)
+    seq = torch.tensor(k_lens, dtype=torch.int32, device=dev)
+    # SURVEY.md 8d: flops = 4 Hq D sum_i [q_i (k_i - q_i) + q_i (q_i + 1) / 2]
+    flops = 4 * hq * D * sum(qi * (ki - qi) + qi * (qi + 1) // 2 for qi, ki in zip(q_lens, k_lens))
+    return dict(out=out, q=q, k=k, v=v, table=table.to(dev), seq=seq, cu_q=cu_q, tile_cu=tile_cu, order=order,
+                B=B, total_tiles=int(tiles.sum()), flops=flops, T=T)
+
+
+def prefill_chunk_lens(budget, lens):
+    """Requests of `lens` packed into one chunk of `budget` new tokens (last one cut), no cache hit."""
+    q, left = [], budget
+    for n in lens:
+        if left <= 0:
+            break
+        q.append(min(n, left))
+        left -= q[-1]
+    return q
+
+
+def run_prefill(res, dev):
+    import bench as _bench
+
+    ctx = _bench.bench_contexts(256)
+    chunk = prefill_chunk_lens(16384, ctx)
+    cases = [
+        ("prefill_14b_chunk16384_bench", chunk, chunk, 40, 8, 256),
+        ("prefill_14b_8x2048", [2048] * 8, [2048] * 8, 40, 8, 256),
+        ("prefill_14b_chunked_hit", [512] * 32, [1024] * 32, 40, 8, 256),
+        ("prefill_14b_tp4_chunk16384", chunk, chunk, 10, 2, 256),
+        ("prefill_0.6b_chunk16384", chunk, chunk, 16, 8, 256),
+    ]
+    for name, ql, kl, hq, hkv, page in cases:
+        c = prefill_case(ql, kl, hq, hkv, page, dev)
+        r = dict(flops=c["flops"], tokens=c["T"], requests=c["B"], q_tiles=c["total_tiles"])
+        for label, impl, order in (("tr_heavy", 2, c["order"]), ("tr_natural", 2, None), ("gen1", 1, None)):
+            f = lambda: ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"],  # noqa: E731
+                                         c["tile_cu"], c["B"], c["total_tiles"], 128 ** -0.5, tile_order=order,
+                                         impl=impl)
+            us = time_us(f, iters=10, warmup=2)
+            r[f"us_{label}"] = us
+            r[f"TFLOPs_{label}"] = c["flops"] / us / 1e6
+            r[f"mfma_frac_{label}"] = c["flops"] / us / 1e6 / MFMA_PEAK_TFLOPS
+        res[name] = r
+        print(name, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
+        del c
+
+
 def run(args):
     dev = torch.device("cuda:0")
     res = {"device": torch.cuda.get_device_name(0), "cus": ops.lib().msgl_device_cu_count()}
     it = 2  # bytes per element
+    if args.only in ("all", "prefill"):
+        run_prefill(res, dev)
+        if args.only == "prefill":
+            Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.out).write_text(json.dumps(res, indent=1))
+            return
     # ---- decode attention, Qwen3-14B TP1 shape, B=256
     for name, B, hq, hkv, page in [("decode_14b_b256_p256", 256, 40, 8, 256), ("decode_14b_b256_p1", 256, 40, 8, 1),
                                    ("decode_14b_tp2_b256", 256, 20, 4, 256), ("decode_14b_tp4_b256", 256, 10, 2, 256),
@@ -151,5 +234,5 @@ def run(args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/microbench.json")
-    ap.add_argument("--only", default="all", choices=["all", "decode"])
+    ap.add_argument("--only", default="all", choices=["all", "decode", "prefill"])
     run(ap.parse_args())

@@ -20,9 +20,15 @@ import bench  # noqa: E402
 
 
 def main():
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    # bench.py measures its roofline launch after the default 5 + 40 steps: context = prompt + 1 + 45
+    ap.add_argument("--advance", type=int, default=46)
+    args = ap.parse_args()
     dev = torch.device("cuda:0")
     B, hq, hkv, D = 256, 40, 8, 128
-    lens = bench.bench_contexts(B)
+    lens = [n + args.advance for n in bench.bench_contexts(B)]
     k, v, table, q = decode_case(B, hq, hkv, lens, 256, dev)
     cap = 4096
     plan = torch.zeros(ops.attn_decode_plan_words(B, cap), dtype=torch.int32, device=dev)
