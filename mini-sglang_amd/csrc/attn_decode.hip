@@ -40,6 +40,13 @@ namespace msgl {
   } while (0)
 
 typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+typedef int I4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor over "everything from base": 48-bit base, stride 0, num_records = 2^32 - 1 bytes
+// (offsets used with it are < 2^31), gfx9 data-format word as used for untyped dword access
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, -1, 0x00020000);
+}
 typedef int I16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(4))) int CInt;                                // constant address space
 typedef int I16a __attribute__((ext_vector_type(16), aligned(16)));
@@ -196,7 +203,7 @@ struct DecodeGeom {
   static constexpr int kMinWavesPerSimd = G <= 2 ? 3 : G <= 5 ? 2 : 1;
 };
 
-template <typename T, int G, bool kRun>
+template <typename T, int G, bool kRun, bool kRS>
 __global__ __launch_bounds__(64 * DecodeGeom<G>::kWavesPerBlock, DecodeGeom<G>::kMinWavesPerSimd) void
 attn_decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
@@ -239,6 +246,20 @@ attn_decode_kernel(const DecodeParams p) {
     const uint16_t* vb = p.v + (int64_t)kvh * p.kv_stride_head + c * 8;
     const uint16_t* kb_row = kb + (int64_t)(4 * r) * p.kv_stride_tok;  // kRun: lane row r starts 4r tokens in
     const uint16_t* vb_row = vb + (int64_t)(4 * r) * p.kv_stride_tok;
+    // kRS (role-ordered tile): the lane's quad "owns" token 4r + own of each 16-token tile; register j of
+    // a tile holds the token at row offset own ^ {0, 1, 3, 2}[j], i.e. j = 0 the owned token, j = 1 the one
+    // its half-mirror partner owns, j = 2 / 3 the ones its row-mirror / ror-8 partners own.  With that
+    // order the 16-lane reduction of the 4 x G scores is a reduce-scatter (G * (2 + 1 + 2) DPP adds
+    // instead of 4 * G * 4): every lane ends with the G scores of ITS token only, the softmax scalar
+    // work is done once per token instead of once per lane, and the probabilities of the other three
+    // tokens come back with three DPP moves per head.
+    const int own = (c >> 2) & 3;
+    const int tok_off[4] = {own, own ^ 1, own ^ 3, own ^ 2};
+    uint32_t voff[4];  // byte offset of (row token, kv head, 16-B piece) from the tile's first token row
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      voff[j] = (uint32_t)((((int64_t)(4 * r + tok_off[j])) * p.kv_stride_tok + (int64_t)kvh * p.kv_stride_head +
+                            c * 8) * 2);
 
     float m[G], l[G], o[G][8];
 #pragma unroll
@@ -283,8 +304,29 @@ attn_decode_kernel(const DecodeParams p) {
     };
     auto load_slots = [&](int tb) -> Slots { return slots_fix(slots_raw(tb), tb); };
     // full tile: every token valid
+    auto pick = [&](const int4& sl4, int idx) -> int {
+      return idx == 0 ? sl4.x : idx == 1 ? sl4.y : idx == 2 ? sl4.z : sl4.w;
+    };
     auto load_tile = [&](const Slots& sl, Tile& t) {
-      if constexpr (kRun) {
+      if constexpr (kRS && kRun) {
+        // buffer loads: a scalar 48-bit base (pool + first slot of the tile) in the descriptor plus the
+        // lane's constant 32-bit offset => no vector address arithmetic and no 64-bit pointers in VGPRs
+        const int64_t tile_bytes = (int64_t)sl * p.kv_stride_tok * 2;
+        const __amdgpu_buffer_rsrc_t kd = make_rsrc(reinterpret_cast<const char*>(p.k) + tile_bytes);
+        const __amdgpu_buffer_rsrc_t vd = make_rsrc(reinterpret_cast<const char*>(p.v) + tile_bytes);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t.k[j] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, (int)voff[j], 0, 0));
+          t.v[j] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, (int)voff[j], 0, 0));
+        }
+      } else if constexpr (kRS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t off = (int64_t)pick(sl, tok_off[j]) * p.kv_stride_tok;
+          t.k[j] = *reinterpret_cast<const V4*>(kb + off);
+          t.v[j] = *reinterpret_cast<const V4*>(vb + off);
+        }
+      } else if constexpr (kRun) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int64_t off = (int64_t)(sl + i) * p.kv_stride_tok;  // scalar
@@ -306,7 +348,7 @@ attn_decode_kernel(const DecodeParams p) {
       if constexpr (kRun) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int tk = 4 * r + i;
+          int tk = 4 * r + (kRS ? tok_off[i] : i);
           if (tb + tk >= t1) tk = 0;
           const int64_t off = (int64_t)(sl + tk) * p.kv_stride_tok;
           t.k[i] = *reinterpret_cast<const V4*>(kb + off);
@@ -318,6 +360,68 @@ attn_decode_kernel(const DecodeParams p) {
     };
     auto compute = [&](const Tile& t, int tb, auto masked_tag) {
       constexpr bool kMasked = decltype(masked_tag)::value;
+      if constexpr (kRS) {
+        float acc[G][4];  // partial dots over this lane's 8 dims, by role
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            float a = Elem<T>::dot2_first(qr[g][0], t.k[j].x);
+            a = Elem<T>::dot2(qr[g][1], t.k[j].y, a);
+            a = Elem<T>::dot2(qr[g][2], t.k[j].z, a);
+            a = Elem<T>::dot2(qr[g][3], t.k[j].w, a);
+            acc[g][j] = a;
+          }
+        }
+        // reduce-scatter over the 16 lanes of the row: the row-mirror partner (own ^ 3) sends its role-2/3
+        // partials, which are this lane's role-0/1 tokens; the half-mirror partner (own ^ 1) its role-1;
+        // then an all-reduce inside the quad.  Every lane of the row is summed exactly once.
+        float sc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float a0 = acc[g][0] + dpp_get<kDppRowMirror>(acc[g][2]);
+          const float a1 = acc[g][1] + dpp_get<kDppRowMirror>(acc[g][3]);
+          float a = a0 + dpp_get<kDppHalfMirror>(a1);
+          a += dpp_get<kDppXor2>(a);
+          a += dpp_get<kDppXor1>(a);
+          sc[g] = a * p.scale_log2;
+        }
+        if constexpr (kMasked) {
+          if (tb + 4 * r + own >= t1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) sc[g] = -INFINITY;
+          }
+        }
+        float pr[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float mx = fmaxf(sc[g], dpp_get<kDppRowMirror>(sc[g]));  // over the row's four tokens
+          mx = fmaxf(mx, dpp_get<kDppHalfMirror>(mx));
+          mx = fmaxf(mx, m[g]);
+          const float alpha = __builtin_amdgcn_exp2f(m[g] - mx);
+          const float pe = __builtin_amdgcn_exp2f(sc[g] - mx);
+          l[g] = fmaf(l[g], alpha, pe);  // this quad's token stream only; quads are summed at the end
+          m[g] = mx;
+          pr[g][0] = pe;
+          pr[g][1] = dpp_get<kDppHalfMirror>(pe);
+          pr[g][2] = dpp_get<kDppRowMirror>(pe);
+          pr[g][3] = dpp_get<kDppRor8>(pe);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[g][e] *= alpha;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float vf[8] = {Elem<T>::lo(t.v[j].x), Elem<T>::hi(t.v[j].x), Elem<T>::lo(t.v[j].y),
+                               Elem<T>::hi(t.v[j].y), Elem<T>::lo(t.v[j].z), Elem<T>::hi(t.v[j].z),
+                               Elem<T>::lo(t.v[j].w), Elem<T>::hi(t.v[j].w)};
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pr[g][j], vf[e], o[g][e]);
+          }
+        }
+        return;
+      }
       float s[G][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -424,6 +528,13 @@ attn_decode_kernel(const DecodeParams p) {
       }
     }
 
+    if constexpr (kRS) {  // l was kept per quad (token stream); m and o are already per row
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        l[g] += dpp_mov<kDppRowMirror>(l[g]);
+        l[g] += dpp_mov<kDppHalfMirror>(l[g]);
+      }
+    }
     // merge the four DPP rows (disjoint token subsets) -> every lane holds the unit's state
 #pragma unroll
     for (int step = 16; step <= 32; step <<= 1) {
@@ -510,7 +621,7 @@ static int resident_waves_of() {
   if (cached == 0) {
     constexpr int kThreads = 64 * DecodeGeom<G>::kWavesPerBlock;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, false>, kThreads, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, false, true>, kThreads, 0) !=
             hipSuccess ||
         nb <= 0) {
       (void)hipGetLastError();
@@ -542,12 +653,26 @@ static int decode_target_slots(int G, int hv, int capacity, int max_bs) {
   return slots < 1 ? 1 : slots;
 }
 
+// A/B switch while the role-ordered reduce-scatter compute is being measured (MSGL_DECODE_RS=0: the
+// all-reduce compute).  Read once.
+static bool decode_use_rs() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MSGL_DECODE_RS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 template <typename T, int G, bool kRun>
 static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
   constexpr int kWPB = DecodeGeom<G>::kWavesPerBlock;
   const int64_t waves = (int64_t)decode_target_slots(G, p.hv, capacity, p.max_bs) * p.hv;
   const int64_t blocks = (waves + kWPB - 1) / kWPB;
-  attn_decode_kernel<T, G, kRun><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
+  if (decode_use_rs())
+    attn_decode_kernel<T, G, kRun, true><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
+  else
+    attn_decode_kernel<T, G, kRun, false><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
   const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
   attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
   return MSGL_OK;

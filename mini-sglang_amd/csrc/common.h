@@ -62,6 +62,13 @@ struct Elem<BF16> {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, a),
                                            __builtin_bit_cast(bf16x2_v, b), acc, false);
   }
+  // a.lo*b.lo + a.hi*b.hi with an inline-constant 0 accumulator (the VOP3P form: the accumulate-in-place
+  // v_dot2c the compiler prefers needs a register zeroed by an extra v_mov first)
+  static __device__ __forceinline__ float dot2_first(uint32_t a, uint32_t b) {
+    float d;
+    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+  }
 };
 
 template <>
@@ -80,6 +87,7 @@ struct Elem<FP16> {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_v, a), __builtin_bit_cast(f16x2_v, b), acc,
                                   false);
   }
+  static __device__ __forceinline__ float dot2_first(uint32_t a, uint32_t b) { return dot2(a, b, 0.f); }
 };
 
 // ---- cross-lane helpers (DPP: full-rate, no LDS) -------------------------------
@@ -90,10 +98,17 @@ __device__ __forceinline__ float dpp_mov(float x) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), kCtrl, 0xf, 0xf, false));
 }
+// same, but with an undefined "old" operand: every lane is written (all rows / banks enabled and each
+// control used here has a source lane for every lane), so no zero has to be materialised for it
+template <int kCtrl>
+__device__ __forceinline__ float dpp_get(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), kCtrl, 0xf, 0xf, true));
+}
 constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;  // i -> 7-i  within each 8 lanes
 constexpr int kDppRowMirror = 0x140;   // i -> 15-i within each 16 lanes
+constexpr int kDppRor8 = 0x128;        // row_ror:8: i -> i^8 within each 16 lanes
 
 // all-reduce (sum) over each aligned group of 8 / 16 lanes
 __device__ __forceinline__ float row8_sum(float x) {

@@ -65,7 +65,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint16_t* out, const uint1
   const int pieces = dim >> 3;
 
   float v[KMAX][8];
+  U4 wq[KMAX];  // weight pieces, requested before the reduction so their latency hides behind it
   float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int p = tir + k * TPR;
+    if (p < pieces) wq[k] = ldg16(weight + p * 8);
+  }
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     const int p = tir + k * TPR;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint16_t* out, const uint1
     const int p = tir + k * TPR;
     if (p < pieces) {
       float w[8], y[8];
-      unpack8<T>(ldg16(weight + p * 8), w);
+      unpack8<T>(wq[k], w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(__fmul_rn(v[k][e], inv), w[e]);
       if (live) stg16(op + p * 8, pack8<T>(y));

@@ -147,10 +147,11 @@ class OfflineRunner:
         eng.sampler.sample(logits, eng.sampler.prepare(batch))
         del logits
 
-    def prefill(self, states: List[RequestState]) -> List:
+    def prefill(self, states: List[RequestState]):
         """Chunked prefill of all requests under the token budget (P/scheduler/prefill.py:65-90:
-        a request cut by the budget continues in the next forward with cached_len advanced)."""
-        outs = []
+        a request cut by the budget continues in the next forward with cached_len advanced).
+        A generator: yields (forward output, requests that got their first token) right after each
+        chunk is enqueued, so a caller can drop a device event between chunks (per-request TTFT)."""
         pending = list(states)
         while pending:
             budget = self.max_extend_tokens
@@ -177,8 +178,7 @@ class OfflineRunner:
             out = self._forward(batch, write, args)  # complete_one: cached_len = device_len, device_len += 1
             if len(finals) != len(reqs):  # undo the +1 of the chunked request: it has not produced a token
                 reqs[-1].device_len -= 1
-            outs.append((out, finals))
-        return outs
+            yield out, finals
 
     def decode_step(self, running: List[RequestState]):
         reqs = [s.req for s in running]

@@ -150,6 +150,12 @@ def run(args):
     dev = torch.device("cuda:0")
     res = {"device": torch.cuda.get_device_name(0), "cus": ops.lib().msgl_device_cu_count()}
     it = 2  # bytes per element
+    if args.only == "rows":
+        res = {}
+        run_rows(res, dev)
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text(json.dumps(res, indent=1))
+        return
     if args.only in ("all", "prefill"):
         run_prefill(res, dev)
         if args.only == "prefill":
@@ -189,6 +195,13 @@ def run(args):
         Path(args.out).parent.mkdir(parents=True, exist_ok=True)
         Path(args.out).write_text(json.dumps(res, indent=1))
         return
+    run_rows(res, dev)
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.out).write_text(json.dumps(res, indent=1))
+
+
+def run_rows(res, dev):
+    it = 2
     # ---- row ops at decode (T=256) and prefill (T=8192) sizes, hidden 5120
     for T in (256, 8192):
         H = 5120
@@ -227,12 +240,10 @@ def run(args):
         for kname in list(res):
             if kname.endswith(f"_T{T}"):
                 print(kname, res[kname], flush=True)
-    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
-    Path(args.out).write_text(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/microbench.json")
-    ap.add_argument("--only", default="all", choices=["all", "decode", "prefill"])
+    ap.add_argument("--only", default="all", choices=["all", "decode", "prefill", "rows"])
     run(ap.parse_args())

@@ -22,11 +22,25 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--top", type=int, default=30)
     ap.add_argument("--csv")
+    ap.add_argument("--steps-by", help="kernel-name substring that occurs once per step (e.g. sample_kernel): "
+                    "summarise only the window spanned by its last --last-steps occurrences, per step")
+    ap.add_argument("--last-steps", type=int, default=10)
     args = ap.parse_args()
     db = sqlite3.connect(args.db)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     rows = cur.execute("select name, start, end from kernels").fetchall() if "name" in cols else []
+    per = 1
+    if args.steps_by and rows:
+        rows.sort(key=lambda r: r[1])
+        marks = [r[2] for r in rows if args.steps_by in r[0]]
+        if len(marks) > args.last_steps:
+            lo, hi = marks[-args.last_steps - 1], marks[-1]
+            rows = [r for r in rows if lo < r[1] <= hi]
+            per = args.last_steps
+            busy = sum(e - s for _, s, e in rows)
+            print(f"# window: last {per} steps by '{args.steps_by}': wall {(hi - lo) / 1e3 / per:.1f} us/step, "
+                  f"kernel busy {busy / 1e3 / per:.1f} us/step, {len(rows) / per:.1f} launches/step")
     stats = {}
     for name, s, e in rows:
         d = stats.setdefault(short(name), [0, 0])
@@ -35,7 +49,7 @@ def main():
     total = sum(v[1] for v in stats.values()) or 1
     lines = ["kernel,calls,total_us,avg_us,percent"]
     for k, (n, t) in sorted(stats.items(), key=lambda kv: -kv[1][1])[: args.top]:
-        lines.append(f"\"{k}\",{n},{t / 1e3:.1f},{t / 1e3 / n:.2f},{100 * t / total:.2f}")
+        lines.append(f"\"{k}\",{n / per:g},{t / 1e3 / per:.1f},{t / 1e3 / n:.2f},{100 * t / total:.2f}")
     print("\n".join(lines))
     # counters
     try:
