@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--page-size", type=int, default=256)
     ap.add_argument("--gemm-tune", default="heuristic")
     ap.add_argument("--out", default="")
+    ap.add_argument("--profile", type=int, default=0, help="cProfile this many decode steps of the same "
+                    "workload instead of the timed run (host-side cost per step)")
     args = ap.parse_args()
 
     from mini_sglang_amd.core import SamplingParams
@@ -55,6 +57,30 @@ def main():
     runner.warmup_prefill()
     # warm-up generate (bench.py:32: llm.generate(["Benchmark: "], SamplingParams()))
     runner.generate([[1, 2, 3, 4]], [SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=8)])
+    if args.profile:
+        import cProfile
+        import pstats
+        import time
+
+        states = [runner.add_request(p, sp) for p, sp in zip(prompts, params)]
+        for _ in runner.prefill(states):
+            pass
+        running = list(states)
+        for _ in range(10):
+            runner.decode_step(running)
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        t0 = time.perf_counter()
+        pr.enable()
+        for _ in range(args.profile):
+            runner.decode_step(running)
+        pr.disable()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"host enqueue {1e3 * (t1 - t0) / args.profile:.3f} ms/step, +sync tail {1e3 * (t2 - t1):.1f} ms total", flush=True)
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        return
     r = runner.generate(prompts, params)
     out_tokens = sum(p.max_tokens for p in params)
     in_tokens = sum(len(p) for p in prompts)
