@@ -207,6 +207,13 @@ int msgl_softmax_temperature(float* probs, const void* logits, const float* temp
 int msgl_sample_top_k_top_p(int32_t* out, const float* probs, const int32_t* top_k,
                             const float* top_p, int64_t rows, int64_t vocab,
                             int64_t probs_stride, uint64_t seed, uint64_t offset, void* stream);
+/* Sample one token per row straight from logits: index ~ softmax(logits[r, :] / temperature[r]), no
+ * top-k / top-p filter, probabilities never materialised (the fused form of the reference's
+ * softmax -> sampling_from_probs pair, P/engine/sample.py:24-44).  Rows 16-byte aligned.
+ * Philox(seed, offset+row). */
+int msgl_sample_from_logits(int32_t* out, const void* logits, const float* temperatures, int64_t rows,
+                            int64_t vocab, int64_t logits_stride, int logits_dtype, uint64_t seed,
+                            uint64_t offset, void* stream);
 
 /* ------------------------------------------------------------------------
  * Tensor-parallel communicator over RCCL (libmsgl_comm.so).  Replaces

@@ -58,6 +58,7 @@ HIP_SIGNATURES = {
     "msgl_argmax_rows": (_i, [_p, _p, _l, _l, _l, _i, _p]),
     "msgl_softmax_temperature": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_sample_top_k_top_p": (_i, [_p, _p, _p, _p, _l, _l, _l, _u64, _u64, _p]),
+    "msgl_sample_from_logits": (_i, [_p, _p, _p, _l, _l, _l, _i, _u64, _u64, _p]),
 }
 
 COMM_SIGNATURES = {

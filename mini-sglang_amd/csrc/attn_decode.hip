@@ -11,10 +11,17 @@
 //   * one wave per unit, all G query heads of the GQA group packed in that wave so each
 //     K/V byte is fetched from HBM exactly once;
 //   * a 256-B K (or V) row of one token = one 16-lane DPP row, 16 B per lane => every
-//     global_load_dwordx4 wave-instruction reads 4 whole token rows (full 128-B lines);
-//   * q.k via v_dot2c_f32_bf16 on the packed data (no unpack), 16-lane all-reduce with four
-//     DPP adds (no LDS), softmax state (m, l, o) kept per 16-lane row over its token subset
-//     and merged across the 4 rows once per unit;
+//     16-B-per-lane wave load reads 4 whole token rows (full 128-B lines); with page_size >= 16
+//     the tile's table entry is ONE scalar load and K/V come through buffer loads (scalar
+//     48-bit tile base in the descriptor + a lane-constant 32-bit offset): no vector address
+//     arithmetic in the loop;
+//   * q.k via v_dot2_f32_bf16 on the packed data (no unpack); the 16-lane reduction is a
+//     reduce-scatter over a role-ordered tile (see the kernel): 5 G DPP adds per tile instead
+//     of 16 G, the softmax scalar work (scale, max, exp) is done once per token instead of
+//     once per lane, probabilities of the row's other three tokens return by 3 G DPP moves,
+//     P.V with v_pk_fma_f32; softmax state (m, o) per 16-lane row over its token subset, l per
+//     quad, merged once per unit.  (The all-reduce formulation it replaces measured the same
+//     at G = 5 and 20 % slower at G = 8: profiles/r01c_microbench_decode_rs{0,1}.json.)
 //   * K/V tiles double-buffered in registers one 16-token tile ahead (8 KB in flight per
 //     wave), page-table slots prefetched two tiles ahead: no LDS, no barriers.
 // Split-KV partials (fp32 o, m, l) go to a workspace and are merged by a second small
@@ -203,7 +210,7 @@ struct DecodeGeom {
   static constexpr int kMinWavesPerSimd = G <= 2 ? 3 : G <= 5 ? 2 : 1;
 };
 
-template <typename T, int G, bool kRun, bool kRS>
+template <typename T, int G, bool kRun>
 __global__ __launch_bounds__(64 * DecodeGeom<G>::kWavesPerBlock, DecodeGeom<G>::kMinWavesPerSimd) void
 attn_decode_kernel(const DecodeParams p) {
   constexpr int D = 128;
@@ -244,9 +251,7 @@ attn_decode_kernel(const DecodeParams p) {
     }
     const uint16_t* kb = p.k + (int64_t)kvh * p.kv_stride_head + c * 8;
     const uint16_t* vb = p.v + (int64_t)kvh * p.kv_stride_head + c * 8;
-    const uint16_t* kb_row = kb + (int64_t)(4 * r) * p.kv_stride_tok;  // kRun: lane row r starts 4r tokens in
-    const uint16_t* vb_row = vb + (int64_t)(4 * r) * p.kv_stride_tok;
-    // kRS (role-ordered tile): the lane's quad "owns" token 4r + own of each 16-token tile; register j of
+    // role-ordered tile: the lane's quad "owns" token 4r + own of each 16-token tile; register j of
     // a tile holds the token at row offset own ^ {0, 1, 3, 2}[j], i.e. j = 0 the owned token, j = 1 the one
     // its half-mirror partner owns, j = 2 / 3 the ones its row-mirror / ror-8 partners own.  With that
     // order the 16-lane reduction of the 4 x G scores is a reduce-scatter (G * (2 + 1 + 2) DPP adds
@@ -308,7 +313,7 @@ attn_decode_kernel(const DecodeParams p) {
       return idx == 0 ? sl4.x : idx == 1 ? sl4.y : idx == 2 ? sl4.z : sl4.w;
     };
     auto load_tile = [&](const Slots& sl, Tile& t) {
-      if constexpr (kRS && kRun) {
+      if constexpr (kRun) {
         // buffer loads: a scalar 48-bit base (pool + first slot of the tile) in the descriptor plus the
         // lane's constant 32-bit offset => no vector address arithmetic and no 64-bit pointers in VGPRs
         const int64_t tile_bytes = (int64_t)sl * p.kv_stride_tok * 2;
@@ -319,27 +324,12 @@ attn_decode_kernel(const DecodeParams p) {
           t.k[j] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, (int)voff[j], 0, 0));
           t.v[j] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, (int)voff[j], 0, 0));
         }
-      } else if constexpr (kRS) {
+      } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t off = (int64_t)pick(sl, tok_off[j]) * p.kv_stride_tok;
           t.k[j] = *reinterpret_cast<const V4*>(kb + off);
           t.v[j] = *reinterpret_cast<const V4*>(vb + off);
-        }
-      } else if constexpr (kRun) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t off = (int64_t)(sl + i) * p.kv_stride_tok;  // scalar
-          t.k[i] = *reinterpret_cast<const V4*>(kb_row + off);
-          t.v[i] = *reinterpret_cast<const V4*>(vb_row + off);
-        }
-      } else {
-        const int v[4] = {sl.x, sl.y, sl.z, sl.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t off = (int64_t)v[i] * p.kv_stride_tok;
-          t.k[i] = *reinterpret_cast<const V4*>(kb + off);
-          t.v[i] = *reinterpret_cast<const V4*>(vb + off);
         }
       }
     };
@@ -348,7 +338,7 @@ attn_decode_kernel(const DecodeParams p) {
       if constexpr (kRun) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int tk = 4 * r + (kRS ? tok_off[i] : i);
+          int tk = 4 * r + tok_off[i];
           if (tb + tk >= t1) tk = 0;
           const int64_t off = (int64_t)(sl + tk) * p.kv_stride_tok;
           t.k[i] = *reinterpret_cast<const V4*>(kb + off);
@@ -360,123 +350,63 @@ attn_decode_kernel(const DecodeParams p) {
     };
     auto compute = [&](const Tile& t, int tb, auto masked_tag) {
       constexpr bool kMasked = decltype(masked_tag)::value;
-      if constexpr (kRS) {
-        float acc[G][4];  // partial dots over this lane's 8 dims, by role
+      float acc[G][4];  // partial dots over this lane's 8 dims, by role
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            float a = Elem<T>::dot2_first(qr[g][0], t.k[j].x);
-            a = Elem<T>::dot2(qr[g][1], t.k[j].y, a);
-            a = Elem<T>::dot2(qr[g][2], t.k[j].z, a);
-            a = Elem<T>::dot2(qr[g][3], t.k[j].w, a);
-            acc[g][j] = a;
-          }
-        }
-        // reduce-scatter over the 16 lanes of the row: the row-mirror partner (own ^ 3) sends its role-2/3
-        // partials, which are this lane's role-0/1 tokens; the half-mirror partner (own ^ 1) its role-1;
-        // then an all-reduce inside the quad.  Every lane of the row is summed exactly once.
-        float sc[G];
+      for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const float a0 = acc[g][0] + dpp_get<kDppRowMirror>(acc[g][2]);
-          const float a1 = acc[g][1] + dpp_get<kDppRowMirror>(acc[g][3]);
-          float a = a0 + dpp_get<kDppHalfMirror>(a1);
-          a += dpp_get<kDppXor2>(a);
-          a += dpp_get<kDppXor1>(a);
-          sc[g] = a * p.scale_log2;
-        }
-        if constexpr (kMasked) {
-          if (tb + 4 * r + own >= t1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) sc[g] = -INFINITY;
-          }
-        }
-        float pr[G][4];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          float mx = fmaxf(sc[g], dpp_get<kDppRowMirror>(sc[g]));  // over the row's four tokens
-          mx = fmaxf(mx, dpp_get<kDppHalfMirror>(mx));
-          mx = fmaxf(mx, m[g]);
-          const float alpha = __builtin_amdgcn_exp2f(m[g] - mx);
-          const float pe = __builtin_amdgcn_exp2f(sc[g] - mx);
-          l[g] = fmaf(l[g], alpha, pe);  // this quad's token stream only; quads are summed at the end
-          m[g] = mx;
-          pr[g][0] = pe;
-          pr[g][1] = dpp_get<kDppHalfMirror>(pe);
-          pr[g][2] = dpp_get<kDppRowMirror>(pe);
-          pr[g][3] = dpp_get<kDppRor8>(pe);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[g][e] *= alpha;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float vf[8] = {Elem<T>::lo(t.v[j].x), Elem<T>::hi(t.v[j].x), Elem<T>::lo(t.v[j].y),
-                               Elem<T>::hi(t.v[j].y), Elem<T>::lo(t.v[j].z), Elem<T>::hi(t.v[j].z),
-                               Elem<T>::lo(t.v[j].w), Elem<T>::hi(t.v[j].w)};
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pr[g][j], vf[e], o[g][e]);
-          }
-        }
-        return;
-      }
-      float s[G][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          float a = Elem<T>::dot2(qr[g][0], t.k[i].x, 0.f);
-          a = Elem<T>::dot2(qr[g][1], t.k[i].y, a);
-          a = Elem<T>::dot2(qr[g][2], t.k[i].z, a);
-          a = Elem<T>::dot2(qr[g][3], t.k[i].w, a);
-          s[g][i] = a;
+          float a = Elem<T>::dot2_first(qr[g][0], t.k[j].x);
+          a = Elem<T>::dot2(qr[g][1], t.k[j].y, a);
+          a = Elem<T>::dot2(qr[g][2], t.k[j].z, a);
+          a = Elem<T>::dot2(qr[g][3], t.k[j].w, a);
+          acc[g][j] = a;
         }
       }
+      // reduce-scatter over the 16 lanes of the row: the row-mirror partner (own ^ 3) sends its role-2/3
+      // partials, which are this lane's role-0/1 tokens; the half-mirror partner (own ^ 1) its role-1;
+      // then an all-reduce inside the quad.  Every lane of the row is summed exactly once.
+      float sc[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[g][i] = row16_sum(s[g][i]) * p.scale_log2;
+        const float a0 = acc[g][0] + dpp_get<kDppRowMirror>(acc[g][2]);
+        const float a1 = acc[g][1] + dpp_get<kDppRowMirror>(acc[g][3]);
+        float a = a0 + dpp_get<kDppHalfMirror>(a1);
+        a += dpp_get<kDppXor2>(a);
+        a += dpp_get<kDppXor1>(a);
+        sc[g] = a * p.scale_log2;
       }
       if constexpr (kMasked) {
-        const int tq = tb + 4 * r;
+        if (tb + 4 * r + own >= t1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (tq + i >= t1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) s[g][i] = -INFINITY;
-          }
+          for (int g = 0; g < G; ++g) sc[g] = -INFINITY;
         }
       }
-      float alpha[G];
+      float pr[G][4];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const float mx = fmaxf(fmaxf(m[g], fmaxf(s[g][0], s[g][1])), fmaxf(s[g][2], s[g][3]));
-        alpha[g] = __builtin_amdgcn_exp2f(m[g] - mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          s[g][i] = __builtin_amdgcn_exp2f(s[g][i] - mx);
-          sum += s[g][i];
-        }
-        l[g] = fmaf(l[g], alpha[g], sum);
+        float mx = fmaxf(sc[g], dpp_get<kDppRowMirror>(sc[g]));  // over the row's four tokens
+        mx = fmaxf(mx, dpp_get<kDppHalfMirror>(mx));
+        mx = fmaxf(mx, m[g]);
+        const float alpha = __builtin_amdgcn_exp2f(m[g] - mx);
+        const float pe = __builtin_amdgcn_exp2f(sc[g] - mx);
+        l[g] = fmaf(l[g], alpha, pe);  // this quad's token stream only; quads are summed at the end
         m[g] = mx;
+        pr[g][0] = pe;
+        pr[g][1] = dpp_get<kDppHalfMirror>(pe);
+        pr[g][2] = dpp_get<kDppRowMirror>(pe);
+        pr[g][3] = dpp_get<kDppRor8>(pe);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[g][e] *= alpha;
       }
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[g][e] *= alpha[g];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float vf[8] = {Elem<T>::lo(t.v[i].x), Elem<T>::hi(t.v[i].x), Elem<T>::lo(t.v[i].y),
-                             Elem<T>::hi(t.v[i].y), Elem<T>::lo(t.v[i].z), Elem<T>::hi(t.v[i].z),
-                             Elem<T>::lo(t.v[i].w), Elem<T>::hi(t.v[i].w)};
+      for (int j = 0; j < 4; ++j) {
+        const float vf[8] = {Elem<T>::lo(t.v[j].x), Elem<T>::hi(t.v[j].x), Elem<T>::lo(t.v[j].y),
+                             Elem<T>::hi(t.v[j].y), Elem<T>::lo(t.v[j].z), Elem<T>::hi(t.v[j].z),
+                             Elem<T>::lo(t.v[j].w), Elem<T>::hi(t.v[j].w)};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[g][e] = fmaf(s[g][i], vf[e], o[g][e]);
+          for (int e = 0; e < 8; ++e) o[g][e] = fmaf(pr[g][j], vf[e], o[g][e]);
         }
       }
     };
@@ -528,12 +458,11 @@ attn_decode_kernel(const DecodeParams p) {
       }
     }
 
-    if constexpr (kRS) {  // l was kept per quad (token stream); m and o are already per row
+    // l was kept per quad (token stream); m and o are already per row
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        l[g] += dpp_mov<kDppRowMirror>(l[g]);
-        l[g] += dpp_mov<kDppHalfMirror>(l[g]);
-      }
+    for (int g = 0; g < G; ++g) {
+      l[g] += dpp_mov<kDppRowMirror>(l[g]);
+      l[g] += dpp_mov<kDppHalfMirror>(l[g]);
     }
     // merge the four DPP rows (disjoint token subsets) -> every lane holds the unit's state
 #pragma unroll
@@ -621,7 +550,7 @@ static int resident_waves_of() {
   if (cached == 0) {
     constexpr int kThreads = 64 * DecodeGeom<G>::kWavesPerBlock;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, false, true>, kThreads, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_decode_kernel<T, G, false>, kThreads, 0) !=
             hipSuccess ||
         nb <= 0) {
       (void)hipGetLastError();
@@ -653,26 +582,12 @@ static int decode_target_slots(int G, int hv, int capacity, int max_bs) {
   return slots < 1 ? 1 : slots;
 }
 
-// A/B switch while the role-ordered reduce-scatter compute is being measured (MSGL_DECODE_RS=0: the
-// all-reduce compute).  Read once.
-static bool decode_use_rs() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MSGL_DECODE_RS");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
-
 template <typename T, int G, bool kRun>
 static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
   constexpr int kWPB = DecodeGeom<G>::kWavesPerBlock;
   const int64_t waves = (int64_t)decode_target_slots(G, p.hv, capacity, p.max_bs) * p.hv;
   const int64_t blocks = (waves + kWPB - 1) / kWPB;
-  if (decode_use_rs())
-    attn_decode_kernel<T, G, kRun, true><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
-  else
-    attn_decode_kernel<T, G, kRun, false><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
+  attn_decode_kernel<T, G, kRun><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
   const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
   attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
   return MSGL_OK;

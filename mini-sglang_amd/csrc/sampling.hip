@@ -389,6 +389,118 @@ __global__ __launch_bounds__(kRowThreads) void sample_kernel(int* __restrict__ o
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// sample directly from logits (temperature only: no top-k / top-p filter)
+//   index ~ softmax(logits / T).  Probabilities are never materialised: with e_i = 2^((x_i - max) k)
+//   the draw is the inverse CDF over the integer masses floor(e_i 2^40) in index order, which is the
+//   same distribution as normalise-then-draw up to fp32 rounding of the normalisation (and, like the
+//   probs path, exact integer arithmetic from there on: identical on every TP rank).
+//   Two passes over the row (max; masses per wave segment) + one wave re-walking its own segment,
+//   16-byte loads throughout.  Wave w owns the contiguous index range [w seg, (w+1) seg).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 exp_mass(float x, float mx, float k) {
+  return (u64)__float2ull_rz(__builtin_amdgcn_exp2f((x - mx) * k) * 1099511627776.0f);  // e in (0, 1]
+}
+
+template <int DT>
+__global__ __launch_bounds__(kRowThreads) void sample_logits_kernel(int* __restrict__ out,
+                                                                    const char* __restrict__ logits,
+                                                                    const float* __restrict__ temperatures,
+                                                                    int64_t vocab, int64_t row_stride_bytes,
+                                                                    u64 seed, u64 offset) {
+  __shared__ float lds_f[kRowThreads / 64];
+  __shared__ u64 lds_w[kRowThreads / 64];
+  __shared__ int s_pick;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t r = blockIdx.x;
+  const void* row = logits + r * row_stride_bytes;
+  constexpr int kWaves = kRowThreads / 64;
+  constexpr int kStep = 64 * 8;  // indices per wave iteration
+  const int64_t seg = ((vocab + kWaves - 1) / kWaves + kStep - 1) / kStep * kStep;
+  const int64_t lo = (int64_t)w * seg, hi = min(vocab, lo + seg);
+
+  float mx = -INFINITY;
+  for (int64_t base = lo + lane * 8; base < hi; base += kStep) {
+    if (base + 8 <= hi) {
+      float f[8];
+      load_logits8<DT>(row, base, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
+    } else {
+      for (int64_t i = base; i < hi; ++i) mx = fmaxf(mx, load_logit<DT>(row, i));
+    }
+  }
+  mx = block_reduce_max(mx, lds_f);
+  const float k = 1.4426950408889634f / temperatures[r];
+
+  auto masses8 = [&](int64_t base, u64 (&mm)[8]) {  // masses of indices base .. base+7 (0 past hi)
+    if (base + 8 <= hi) {
+      float f[8];
+      load_logits8<DT>(row, base, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mm[e] = exp_mass(f[e], mx, k);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mm[e] = base + e < hi ? exp_mass(load_logit<DT>(row, base + e), mx, k) : 0ull;
+    }
+  };
+  u64 wave_mass = 0;
+  for (int64_t base = lo + lane * 8; base < hi; base += kStep) {
+    u64 mm[8];
+    masses8(base, mm);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wave_mass += mm[e];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t l32 = __shfl_xor((uint32_t)wave_mass, d, 64);
+    const uint32_t h32 = __shfl_xor((uint32_t)(wave_mass >> 32), d, 64);
+    wave_mass += ((u64)h32 << 32) | l32;
+  }
+  if (lane == 0) lds_w[w] = wave_mass;
+  if (tid == 0) s_pick = -1;
+  __syncthreads();
+  u64 total = 0, before = 0;
+  for (int i = 0; i < kWaves; ++i) {
+    if (i < w) before += lds_w[i];
+    total += lds_w[i];
+  }
+  const uint32_t x = Philox::draw(seed, offset + (u64)r);
+  const u64 u = (total >> 32) * (u64)x + (((total & 0xffffffffull) * (u64)x) >> 32);  // [0, total)
+  if (total > 0 && u >= before && u < before + wave_mass) {  // exactly one wave
+    u64 run = before;
+    for (int64_t base0 = lo; base0 < hi; base0 += kStep) {
+      u64 mm[8];
+      masses8(base0 + lane * 8, mm);
+      u64 mine = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mine += mm[e];
+      u64 incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u64 o = shfl_up_u64(incl, d);
+        if (lane >= d) incl += o;
+      }
+      const u64 chunk = shfl_u64(incl, 63);
+      if (u < run + chunk) {
+        u64 start = run + incl - mine;  // mass before this lane's 8 indices
+        if (mine > 0 && u >= start && u < start + mine) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (u >= start && u < start + mm[e]) s_pick = (int)(base0 + lane * 8 + e);
+            start += mm[e];
+          }
+        }
+        break;
+      }
+      run += chunk;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) out[r] = s_pick < 0 ? 0 : s_pick;  // degenerate row (no mass): first index
+}
+
 }  // namespace msgl
 
 using namespace msgl;
@@ -454,5 +566,31 @@ extern "C" int msgl_sample_top_k_top_p(int32_t* out, const float* probs, const i
   sample_kernel<<<dim3((unsigned)rows), dim3(kRowThreads), 0, static_cast<hipStream_t>(stream)>>>(
       out, probs, top_k, top_p, vocab, probs_stride, (u64)seed, (u64)offset);
   MSGL_CHECK_LAUNCH("sample_top_k_top_p");
+  return MSGL_OK;
+}
+
+extern "C" int msgl_sample_from_logits(int32_t* out, const void* logits, const float* temperatures, int64_t rows,
+                                       int64_t vocab, int64_t logits_stride, int logits_dtype, uint64_t seed,
+                                       uint64_t offset, void* stream) {
+  MSGL_REQUIRE(rows >= 0, "sample_from_logits: negative rows");
+  if (rows == 0) return MSGL_OK;
+  MSGL_REQUIRE(out && logits && temperatures, "sample_from_logits: null pointer");
+  MSGL_REQUIRE(vocab >= 1 && vocab < (1ll << 31) && rows < (1ll << 31), "sample_from_logits: bad shape");
+  const int esz = logits_dtype == MSGL_F32 ? 4 : 2;
+  MSGL_REQUIRE(aligned16(logits) && (logits_stride * esz) % 16 == 0,
+               "sample_from_logits: rows must be 16-byte aligned (stride %lld elements)", (long long)logits_stride);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 g((unsigned)rows), b(kRowThreads);
+  if (logits_dtype == MSGL_F32)
+    sample_logits_kernel<MSGL_F32><<<g, b, 0, s>>>(out, (const char*)logits, temperatures, vocab, logits_stride * esz, (u64)seed, (u64)offset);
+  else if (logits_dtype == MSGL_BF16)
+    sample_logits_kernel<MSGL_BF16><<<g, b, 0, s>>>(out, (const char*)logits, temperatures, vocab, logits_stride * esz, (u64)seed, (u64)offset);
+  else if (logits_dtype == MSGL_FP16)
+    sample_logits_kernel<MSGL_FP16><<<g, b, 0, s>>>(out, (const char*)logits, temperatures, vocab, logits_stride * esz, (u64)seed, (u64)offset);
+  else {
+    set_error("sample_from_logits: unsupported dtype code %d", logits_dtype);
+    return MSGL_EINVAL;
+  }
+  MSGL_CHECK_LAUNCH("sample_from_logits");
   return MSGL_OK;
 }

@@ -116,6 +116,10 @@ class _SamplingNamespace:
     def sampling_from_probs(self, probs, **_kw):
         return self._sample(probs, None, None)
 
+    def sampling_from_logits(self, logits, temperature, **_kw):
+        """Fused softmax(logits / T) + draw (same Philox stream as the probs functions)."""
+        return ops.sample_from_logits(logits, temperature, torch.initial_seed(), self._next_offset(logits.shape[0]))
+
     def top_k_sampling_from_probs(self, probs, top_k, **_kw):
         return self._sample(probs, top_k, None)
 

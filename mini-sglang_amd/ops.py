@@ -318,6 +318,21 @@ def sample_top_k_top_p(probs: torch.Tensor, top_k: Optional[torch.Tensor], top_p
     return out
 
 
+def sample_from_logits(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
+    """index ~ softmax(logits / T) per row, fused (no probs tensor); rows must be 16-byte aligned."""
+    _need_cuda(logits, temperatures)
+    assert logits.dim() == 2 and logits.stride(1) == 1 and temperatures.dtype == torch.float32
+    assert temperatures.numel() == logits.shape[0]
+    out = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    check(
+        lib().msgl_sample_from_logits(out.data_ptr(), logits.data_ptr(), temperatures.data_ptr(), logits.shape[0],
+                                      logits.shape[1], logits.stride(0), _logits_dt(logits),
+                                      seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF, _stream()),
+        "sample_from_logits",
+    )
+    return out
+
+
 # ---------------------------------------------------------------------------- projection GEMMs
 _GEMM_WS: dict = {}
 GEMM_WORKSPACE_BYTES = 128 << 20  # stream-K / split-K solutions need scratch; one buffer per device

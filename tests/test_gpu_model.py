@@ -151,3 +151,55 @@ def test_sampling_path_runs_and_is_seed_deterministic(dev):
         eng.shutdown()
     assert outs[0] == outs[1]
     assert all(0 <= t < 1024 for row in outs[0] for t in row)
+
+
+@pytest.mark.parametrize("page_size,new_tokens", [(1, 32), (16, 12)])
+def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_tokens):
+    """BASELINE.json configs[0] at the real Qwen3-0.6B dimensions: seeded N(0, 0.02^2)
+    weights, one prompt of 32 ids randint(0, 10000) seed 0, temperature 0, 32 new tokens at page_size 1 (12 at
+    page_size 16: the oracle re-materialises 2.4 GB of fp32 weights per forward).
+    The GPU run (chunk-free prefill + graph-replayed decode steps) is teacher-forced through the CPU oracle:
+    logits within 8e-2 at every step (28 bf16 layers, logit std 0.64: the tiny models' 3e-2 was exceeded by
+    16 of 151 936 logits, max 4.3e-2), greedy id equal wherever the oracle's margin exceeds twice that,
+    out_loc trace = the page table's slots for the request's positions, K pool equal to the oracle's."""
+    import random
+
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.model import PRESETS
+
+    cfg = EngineConfig(model=PRESETS["qwen3-0.6b"], dtype=torch.bfloat16, max_running_req=4, page_size=page_size,
+                       cuda_graph_bs=[1], max_seq_len_override=256, num_page_override=1024 // page_size, seed=42)
+    eng = Engine(cfg, dev)
+    eng.kv_cache._kv_buffer.zero_()
+    rnd = random.Random(0)
+    prompt = [rnd.randint(0, 10000) for _ in range(32)]
+    rec = []
+    tol = 8e-2
+    ids, stats, runner = run(eng, [prompt], new_tokens, record=rec)
+    assert len(ids[0]) == new_tokens and stats["decode_steps"] == new_tokens - 1
+    m = eng.cfg.model
+    w = ref_model.weights_from_device_model(eng.model)
+    table = eng.page_table.cpu()
+    slots = eng.kv_cache._kv_buffer.shape[2] * eng.kv_cache._kv_buffer.shape[3]
+    kp = [torch.zeros((slots, m.num_kv_heads, m.head_dim), dtype=torch.bfloat16) for _ in range(m.num_layers)]
+    vp = [torch.zeros_like(k) for k in kp]
+    row = rec[0]["rows"][0]
+    sure_n = same_n = 0
+    for step, r in enumerate(rec):
+        # KV block indices: the slots this forward writes are the table's entries for its positions
+        assert torch.equal(r["out_loc"].long(), table[row, r["positions"].long()].long())
+        logits = ref_model.forward(m, w, r["input_ids"], r["positions"], r["out_loc"], kp, vp, table, r["rows"],
+                                   r["k_lens"], r["q_lens"], r["phase"] == "prefill").float()[: r["size"]]
+        torch.testing.assert_close(r["logits"], logits, atol=tol, rtol=tol)
+        top2 = logits.topk(2, dim=-1).values
+        sure = bool((top2[0, 0] - top2[0, 1]) > 2 * tol)
+        same = int(r["logits"].argmax(-1)[0]) == int(logits.argmax(-1)[0])
+        assert same or not sure, f"step {step}: greedy id differs at a margin of {float(top2[0, 0] - top2[0, 1])}"
+        sure_n += sure
+        same_n += same
+        assert ids[0][step] == int(r["logits"].argmax(-1)[0])  # the id fed back is the argmax of these logits
+    assert same_n >= sure_n
+    dev_k = eng.kv_cache._kv_buffer[0].cpu().view(m.num_layers, slots, m.num_kv_heads, m.head_dim)
+    for li in (0, m.num_layers // 2, m.num_layers - 1):
+        torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=3e-2, rtol=3e-2)
+    eng.shutdown()

@@ -126,3 +126,56 @@ def test_sampling_per_row_parameters(ops, dev):
         out = ops.sample_top_k_top_p(pd, tk, tp, 99, off).cpu().long()
         for r in range(8):
             assert support[r, out[r]], (r, int(out[r]))
+
+
+# ---------------------------------------------------------------- fused softmax + draw (temperature only)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("temperature", [0.6, 1.0, 1.7])
+def test_sample_from_logits_distribution(ops, dev, dtype, temperature):
+    """One row replicated N times: frequencies of the fused kernel against softmax(logits / T) of the oracle."""
+    g = torch.Generator().manual_seed(11)
+    V, N = 4096, 40000
+    logits = (torch.randn(V, generator=g) * 2.5).to(dtype)
+    t = torch.full((N,), temperature, dtype=torch.float32)
+    out = ops.sample_from_logits(logits.unsqueeze(0).repeat(N, 1).to(dev), t.to(dev), 4321, 0).cpu().long()
+    assert out.min() >= 0 and out.max() < V
+    expect = ref_ops.softmax_temperature_ref(logits.unsqueeze(0), t[:1])[0]
+    _chi2_ok(torch.bincount(out, minlength=V), expect, N)
+
+
+@pytest.mark.parametrize("vocab", [151936, 128256, 33336, 1000, 8])
+def test_sample_from_logits_edges(ops, dev, vocab):
+    """T -> 0 rows return the (unique) argmax; results are a function of (seed, offset) only; the graph path's
+    fp32 buffer view (row stride > vocab) and a ragged last wave segment are covered by the vocab list."""
+    g = torch.Generator().manual_seed(vocab)
+    rows = 6
+    pad = 24 if vocab % 8 == 0 else 0
+    buf = torch.randn((rows, vocab + pad), generator=g) * 3
+    logits = buf[:, :vocab]
+    dl = buf.to(dev)[:, :vocab]
+    cold = torch.full((rows,), 1e-6, dtype=torch.float32, device=dev)
+    assert torch.equal(ops.sample_from_logits(dl, cold, 42, 0).cpu(), ref_ops.argmax_ref(logits))
+    warm = torch.full((rows,), 0.8, dtype=torch.float32, device=dev)
+    a = ops.sample_from_logits(dl, warm, 42, 100)
+    b = ops.sample_from_logits(dl, warm, 42, 100)
+    assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < vocab
+    draws = torch.stack([ops.sample_from_logits(dl, warm, 42, 1000 + 8 * i) for i in range(12)])
+    if vocab > 8:
+        assert len(set(draws[:, 0].tolist())) > 1  # the offset moves the Philox stream
+
+
+def test_sample_from_logits_matches_probs_path_statistically(ops, dev):
+    """Same logits through softmax -> sampling_from_probs and through the fused kernel: the two empirical
+    distributions agree (two-sample chi-square on the pooled top cells)."""
+    g = torch.Generator().manual_seed(17)
+    V, N = 2048, 30000
+    logits = torch.randn(V, generator=g) * 2
+    t = torch.full((N,), 0.6, dtype=torch.float32, device=dev)
+    dl = logits.unsqueeze(0).repeat(N, 1).to(dev)
+    a = torch.bincount(ops.sample_from_logits(dl, t, 5, 0).cpu().long(), minlength=V).double()
+    b = torch.bincount(ops.sample_top_k_top_p(ops.softmax_temperature(dl, t), None, None, 6, 0).cpu().long(),
+                       minlength=V).double()
+    big = (a + b) >= 20
+    chi2 = (((a - b) ** 2)[big] / (a + b)[big]).sum().item()
+    dof = int(big.sum()) - 1
+    assert chi2 < dof + 6 * (2 * dof) ** 0.5 + 10, (chi2, dof)
