@@ -216,6 +216,19 @@ int msgl_sample_from_logits(int32_t* out, const void* logits, const float* tempe
                             uint64_t offset, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Weight-streaming projection GEMM for small decode batches (1 <= M <= 64):
+ * out[M, N] = x[M, K] . w[N, K]^T, row-major, 16-bit in/out, fp32 accumulate -- the reference's
+ * F.linear at P/layers/linear.py:32,103,124 for decode-sized M, where the BLAS library's kernels
+ * stream weights at 1.4-4.4 TB/s.  N % 16 == 0, K % 64 == 0, leading dimensions in elements
+ * (ldx, ldw multiples of 8, ldo of 4).  Two tuning knobs, results do not depend on them beyond fp32
+ * summation order: `slices` = waves splitting K inside a workgroup (<= K/64 and <= 16, 8 or 4 as
+ * the register footprint grows), `row_tiles` = 16-row weight tiles per wave (1, 2, 4; N must be a
+ * multiple of 16 row_tiles).  Deterministic, no workspace, capturable.
+ * ---------------------------------------------------------------------- */
+int msgl_skinny_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
+                        int64_t ldw, int64_t ldo, int dtype, int slices, int row_tiles, void* stream);
+
+/* ------------------------------------------------------------------------
  * Tensor-parallel communicator over RCCL (libmsgl_comm.so).  Replaces
  * NCCLWrapper (C/src/pynccl.cu:72-175) / init_pynccl (P/kernel/pynccl.py:47-78).
  * ---------------------------------------------------------------------- */

@@ -34,6 +34,7 @@ HIP_SOURCES = [
     "attn_decode.hip",
     "attn_prefill.hip",
     "sampling.hip",
+    "gemm_skinny.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]
 GEMM_SOURCES = ["gemm.cpp"]

@@ -177,6 +177,13 @@ class DenseDecoder:
                 x = torch.randn((bs, k), device=self.device, dtype=torch.float32).to(self.dtype)
                 r = ops.gemm_tune(x, ws, max_candidates=cand, iters=8)
                 r["name"] = name
+                if bs <= ops.SKINNY_MAX_M:  # hand-written weight-streaming kernel vs the library's best
+                    sk = ops.skinny_tune(x, ws, r["best_us"])
+                    r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
+                             skinny_used=sk["used"])
+                    if sk["used"]:
+                        r["library_best_us"], r["best_us"] = r["best_us"], sk["skinny_us"]
+                        r["kernel"] = f"msgl::skinny_gemm_kernel[slices {sk['slices']}, row tiles {sk['row_tiles']}]"
                 report.append(r)
                 if log is not None:
                     log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "

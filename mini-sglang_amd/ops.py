@@ -359,12 +359,88 @@ def _gemm_args(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]):
     return out, M, N, K
 
 
+# (M, N, K, ldx, ldw, dtype code) -> (k-slices, row tiles) of the hand-written weight-streaming kernel, for the
+# shapes where skinny_tune() measured it faster than the library's best solution
+_SKINNY_PLAN: dict = {}
+SKINNY_MAX_M = 64
+
+
+def skinny_supported(M: int, N: int, K: int) -> bool:
+    return 1 <= M <= SKINNY_MAX_M and N % 16 == 0 and K % 64 == 0
+
+
+def skinny_linear(x: torch.Tensor, w: torch.Tensor, slices: int, out: Optional[torch.Tensor] = None,
+                  row_tiles: int = 1) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_skinny_gemm_nt (M <= 64)."""
+    out, M, N, K = _gemm_args(x, w, out)
+    check(
+        lib().msgl_skinny_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                  out.stride(0), _dt(x), slices, row_tiles, _stream()),
+        "skinny_gemm_nt",
+    )
+    return out
+
+
+def skinny_candidates(M: int, N: int, K: int):
+    """(k-slices, row tiles per wave) settings the kernel accepts for this shape (csrc/gemm_skinny.hip)."""
+    mt = 1 if M <= 16 else 2 if M <= 32 else 4
+    out = []
+    for nt in (1, 2, 4):
+        if N % (16 * nt):
+            continue
+        cap = min(16 if mt * nt <= 2 else 8 if mt * nt <= 8 else 4, K // 64)
+        out += [(sl, nt) for sl in (1, 2, 4, 8, 16) if sl <= cap]
+    return out
+
+
+def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> dict:
+    """Time the weight-streaming kernel over its (k-slices, row tiles) settings on rotating weights (as
+    gemm_tune does) and plan it for this shape if it beats `library_us`.  Synchronises; call before capture."""
+    weights = list(weights)
+    w0 = weights[0]
+    M, K = x.shape
+    N = w0.shape[0]
+    res = dict(M=M, N=N, K=K, library_us=library_us, skinny_us=None, slices=0, row_tiles=0, used=False)
+    if not skinny_supported(M, N, K):
+        return res
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+
+    def time_us(sl, nt, rounds):
+        skinny_linear(x, w0, sl, out, nt)  # warm-up
+        ts = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(iters):
+                skinny_linear(x, weights[(i + 1) % len(weights)], sl, out, nt)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / iters)
+        return min(ts)
+
+    ranked = sorted((time_us(sl, nt, 1), sl, nt) for sl, nt in skinny_candidates(M, N, K))
+    best = min((time_us(sl, nt, 3), sl, nt) for _, sl, nt in ranked[:4])  # re-time the best few
+    res.update(skinny_us=best[0], slices=best[1], row_tiles=best[2])
+    key = (M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    if best[0] < library_us:
+        _SKINNY_PLAN[key] = (best[1], best[2])
+        res["used"] = True
+    else:
+        _SKINNY_PLAN.pop(key, None)
+    return res
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, N] = x[M, K] @ w[N, K]^T (the reference's `F.linear`, P/layers/linear.py:32) through
-    msgl_gemm_nt: the tuned library solution for the shape if gemm_tune() ran, else the heuristic."""
+    """out[M, N] = x[M, K] @ w[N, K]^T (the reference's `F.linear`, P/layers/linear.py:32): the hand-written
+    weight-streaming kernel where skinny_tune() planned it (decode batches <= 64), else msgl_gemm_nt with the
+    tuned library solution for the shape if gemm_tune() ran, else the library's heuristic."""
     out, M, N, K = _gemm_args(x, w, out)
     if M == 0:
         return out
+    if M <= SKINNY_MAX_M and _SKINNY_PLAN:
+        plan = _SKINNY_PLAN.get((M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return skinny_linear(x, w, plan[0], out, plan[1])
     ws = gemm_workspace(x.device)
     _lib.check_gemm(
         _lib.gemm_lib().msgl_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),

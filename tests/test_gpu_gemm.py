@@ -87,3 +87,65 @@ def test_linear_under_graph_capture(ops, dev):
 def test_linear_rejects_cpu_tensors(ops):
     with pytest.raises(RuntimeError):
         ops.linear(torch.zeros((2, 8), dtype=torch.bfloat16), torch.zeros((4, 8), dtype=torch.bfloat16))
+
+
+# ---------------------------------------------------------------- hand-written weight-streaming kernel (M <= 64)
+@pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(7168, 5120), (5120, 17408), (48, 64), (1024, 1024), (5120, 4352), (256, 192)])
+def test_skinny_gemm_matches_fp32_reference(ops, dev, M, N, K):
+    """Every (k-slices, row tiles) setting, ragged slices (K/64 not divisible by the slice count), the three column-tile
+    widths (M <= 16, 32, 64) and padded columns (M not a multiple of 16)."""
+    g = torch.Generator(device=dev).manual_seed(M * 131 + N + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    ref = _ref(x, w)
+    assert ops.skinny_supported(M, N, K)
+    cands = ops.skinny_candidates(M, N, K)
+    assert cands
+    for sl, nt in cands:
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.skinny_linear(x, w, sl, out, nt)
+        _check(out, ref)
+        again = ops.skinny_linear(x, w, sl, row_tiles=nt)
+        assert torch.equal(out, again)  # fixed summation order
+
+
+def test_skinny_gemm_fp16_and_strides(ops, dev):
+    g = torch.Generator(device=dev).manual_seed(5)
+    big = (torch.randn((24, 3 * 512), generator=g, device=dev) * 0.5).to(torch.float16)
+    x = big[:, 512:1024]  # row stride 1536
+    w_all = (torch.randn((768, 1024), generator=g, device=dev) * 0.05).to(torch.float16)
+    w = w_all[:, :512]    # row stride 1024
+    fused = torch.zeros((24, 2048), dtype=torch.float16, device=dev)
+    out = ops.skinny_linear(x, w, 4, out=fused[:, 256:1024], row_tiles=2)
+    _check(out, _ref(x, w))
+    assert fused[:, :256].abs().max().item() == 0 and fused[:, 1024:].abs().max().item() == 0
+
+
+def test_skinny_gemm_rejects_what_it_cannot_do(ops, dev):
+    x = torch.zeros((8, 128), dtype=torch.bfloat16, device=dev)
+    w = torch.zeros((40, 128), dtype=torch.bfloat16, device=dev)   # N % 16 != 0
+    with pytest.raises(RuntimeError):
+        ops.skinny_linear(x, w, 1)
+    w = torch.zeros((48, 128), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.skinny_linear(x, w, 4)                                 # more slices than 64-k blocks
+    x65 = torch.zeros((65, 128), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.skinny_linear(x65, w, 1)
+
+
+def test_skinny_tune_plans_only_when_faster_and_linear_dispatches(ops, dev):
+    g = torch.Generator(device=dev).manual_seed(9)
+    M, N, K = 8, 5120, 17408
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    ws = [(torch.randn((N, K), generator=g, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
+    lib = ops.gemm_tune(x, ws, max_candidates=-8, iters=5)
+    rep = ops.skinny_tune(x, ws, lib["best_us"])
+    key = (M, N, K, x.stride(0), ws[0].stride(0), ops._dt(x))
+    assert rep["skinny_us"] is not None and rep["used"] == (rep["skinny_us"] < lib["best_us"])
+    assert (key in ops._SKINNY_PLAN) == rep["used"]
+    _check(ops.linear(x, ws[0]), _ref(x, ws[0]))  # whichever path was planned
+    print(f"down-proj M=8: library {lib['best_us']:.1f} us, skinny {rep['skinny_us']:.1f} us "
+          f"(slices {rep['slices']}, row tiles {rep['row_tiles']})")
+    ops._SKINNY_PLAN.pop(key, None)

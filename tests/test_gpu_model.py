@@ -200,6 +200,6 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
         assert ids[0][step] == int(r["logits"].argmax(-1)[0])  # the id fed back is the argmax of these logits
     assert same_n >= sure_n
     dev_k = eng.kv_cache._kv_buffer[0].cpu().view(m.num_layers, slots, m.num_kv_heads, m.head_dim)
-    for li in (0, m.num_layers // 2, m.num_layers - 1):
-        torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=3e-2, rtol=3e-2)
+    for li in (0, m.num_layers // 2, m.num_layers - 1):  # one bf16 ulp of a K element of magnitude 4 is 3e-2
+        torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=tol, rtol=tol)
     eng.shutdown()

@@ -50,6 +50,10 @@ def main():
             t0 = time.perf_counter()
             r = ops.gemm_tune(x, ws, max_candidates=cand, iters=10)
             r["tune_s"] = time.perf_counter() - t0
+            if bs <= ops.SKINNY_MAX_M:
+                sk = ops.skinny_tune(x, ws, r["best_us"], iters=10)
+                r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
+                         skinny_used=sk["used"])
             got = ops.linear(x, ws[0]).float()
             ref = x.float() @ ws[0].float().t()
             err = (got - ref).abs().max().item()
@@ -60,7 +64,11 @@ def main():
                      default_tbps=wbytes / r["default_us"] / 1e6, best_tbps=wbytes / r["best_us"] / 1e6)
             rows.append(r)
             tot_def += r["default_us"] * per_step[name]
-            tot_best += r["best_us"] * per_step[name]
+            eff = min(r["best_us"], r.get("skinny_us") or 1e30)
+            tot_best += eff * per_step[name]
+            if r.get("skinny_us"):
+                print(f"      skinny: {r['skinny_us']:8.1f} us ({wbytes / r['skinny_us'] / 1e6:.2f} TB/s) slices "
+                      f"{r['skinny_slices']} row tiles {r['skinny_row_tiles']}  {'<< used' if r['skinny_used'] else ''}", flush=True)
             print(f"bs={bs:4d} {name:8s} N={N:6d} K={K:6d}: heuristic {r['default_us']:8.1f} us "
                   f"({r['default_tflops']:6.0f} TF, {r['default_tbps']:.2f} TB/s) -> best {r['best_us']:8.1f} us "
                   f"({r['best_tflops']:6.0f} TF, {r['best_tbps']:.2f} TB/s) of {r['tried']} in {r['tune_s']:.1f}s "
