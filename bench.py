@@ -152,6 +152,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="fill the KV pool with random data instead")
     ap.add_argument("--no-prefill-roofline", action="store_true", help="skip the prefill-attention MFMA measurement")
+    ap.add_argument("--small-batches", type=int, nargs="*", default=[1, 8, 32],
+                    help="also report ms per decode step at these batch sizes (latency regime; [] to skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +191,8 @@ def main() -> None:
     use_graph = os.environ.get("MSGL_BENCH_NO_GRAPH", "0") != "1"
     max_seq = 4096  # max_seq_len_override of the reference bench
     ecfg = EngineConfig(model=mcfg, dtype=torch.bfloat16, tp_rank=rank, tp_size=world, max_running_req=B,
-                        cuda_graph_bs=[B] if use_graph else [], page_size=args.page_size,
+                        cuda_graph_bs=sorted(set([b for b in args.small_batches if b < B] + [B])) if use_graph else [],
+                        page_size=args.page_size,
                         max_seq_len_override=max_seq, comm=comm, memory_ratio=0.9,
                         gemm_tune=os.environ.get("MSGL_GEMM_TUNE", "full"))
     engine, err = None, None
@@ -215,7 +218,7 @@ def main() -> None:
     rnd = random.Random(1234)
     prompts = [[rnd.randint(0, 10000) for _ in range(n)] for n in contexts]
     total_steps = args.steps + args.warmup
-    sp = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=total_steps + 8) for _ in range(B)]
+    sp = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=total_steps + 8 + 13 * len(args.small_batches)) for _ in range(B)]
     states = [runner.add_request(p, s) for p, s in zip(prompts, sp)]
 
     # ---------------- prefill (untimed for `value`; yields TTFT) ----------------
@@ -292,6 +295,25 @@ def main() -> None:
     step_bytes = engine.model.streamed_bytes_per_step() + (S + B) * kv_tok + B * mcfg.vocab_size * it
     step_gbps = step_bytes / (ms_per_step * 1e-3) / 1e9
 
+    # ---------------- latency regime: the same model at small decode batches (not part of `value`) --------
+    small = {}
+    if use_graph:
+        for sb in [b for b in args.small_batches if b < B]:
+            sub = running[:sb]
+            for _ in range(3):
+                runner.decode_step(sub)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                runner.decode_step(sub)
+            barrier()
+            small[str(sb)] = (time.perf_counter() - t1) * 1e3 / 10
+        if world > 1:
+            for k in list(small):
+                t = torch.tensor([small[k]], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                small[k] = float(t[0])
+
     traffic, traffic_src = pmc_traffic(attn_bytes)
     prefill_roofline = None
     if rank == 0 and not args.no_prefill_roofline:
@@ -311,6 +333,7 @@ def main() -> None:
             "batch": B, "parallelism": f"tp{world}", "mean_context": S / B,
         },
         "ttft_p50_ms": ttft_p50,
+        "small_batch_ms_per_step": small,
         "roofline": {
             "bound": "hbm", "kernel": "attn_decode_kernel (+merge), one layer", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -329,7 +352,9 @@ def main() -> None:
         "shapes": [dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], heuristic_us=round(r["default_us"], 1),
                         tuned_us=round(r["best_us"], 1), candidates=r["tried"],
                         tflops=round(2.0 * r["M"] * r["N"] * r["K"] / r["best_us"] / 1e6, 1),
-                        weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2)) for r in engine.gemm_report],
+                        weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2),
+                        **({"hand_written": r["kernel"], "library_best_us": round(r["library_best_us"], 1)}
+                           if r.get("skinny_used") else {})) for r in engine.gemm_report],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         engine.shutdown()

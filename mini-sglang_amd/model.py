@@ -163,7 +163,8 @@ class DenseDecoder:
         solution).  Weights of different layers are rotated so candidates are timed from HBM."""
         if mode == "off" or not batch_sizes:
             return []
-        cand = {"heuristic": -16, "full": 0}[mode]
+        # "full" pays only where a step is long: the largest batch; smaller graphs take the library's top 16
+        cands = {bs: ({"heuristic": -16, "full": 0}[mode] if bs == max(batch_sizes) else -16) for bs in batch_sizes}
         report = []
         step = max(1, len(self.layers) // 8)
         pick = self.layers[::step][:8]
@@ -175,7 +176,7 @@ class DenseDecoder:
         for bs in batch_sizes:
             for name, ws, k in groups:
                 x = torch.randn((bs, k), device=self.device, dtype=torch.float32).to(self.dtype)
-                r = ops.gemm_tune(x, ws, max_candidates=cand, iters=8)
+                r = ops.gemm_tune(x, ws, max_candidates=cands[bs], iters=8)
                 r["name"] = name
                 if bs <= ops.SKINNY_MAX_M:  # hand-written weight-streaming kernel vs the library's best
                     sk = ops.skinny_tune(x, ws, r["best_us"])
