@@ -238,7 +238,9 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   // max_candidates: 0 = every library solution, n > 1 = the first n of them, -n = the top n of the
   // library's own heuristic ranking (cheap: tens of candidates), 1 = heuristic pick only
   std::vector<hipblasLtMatmulHeuristicResult_t> all;
-  const bool split_search = (max_candidates == 0 || max_candidates > 1) && split_k_search != 0;
+  // split-K variants are tried in every search mode: the heuristic ranking never proposes them, and they are
+  // what the K = 17408 down-projection needs at every M (77 vs 127 us at M = 64 .. 256)
+  const bool split_search = max_candidates != 1 && split_k_search != 0;
   if (max_candidates == 0 || max_candidates > 1) {
     hipblasStatus_t st = hipblaslt_ext::getAllAlgos(h, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T,
                                                     HIPBLAS_OP_N, t, t, t, t, HIPBLAS_COMPUTE_32F, all);
@@ -277,7 +279,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   }
 
   // split-K variants of every supported solution (the few-tile shapes N <= 8192 of a decode step leave
-  // most CUs idle otherwise).  Only in the exhaustive modes.
+  // most CUs idle otherwise).
   if (split_search) {
     GemmBox* box = new GemmBox();
     new (box->raw) hipblaslt_ext::Gemm(h, base.prob->desc, &alpha, w_list[0], base.prob->a, x, base.prob->b, &beta,
