@@ -161,7 +161,10 @@ class GraphRunner:
             batch.input_ids, batch.out_loc, batch.positions = self.input_ids[:bs], self.out_loc[:bs], self.positions[:bs]
             with engine.ctx.forward_batch(batch):
                 self.logits[:bs] = engine.model.forward(engine.ctx, batch)
-                with torch.cuda.graph(graph, pool=pool, stream=engine.stream):
+                # with a communicator inside the graph, RCCL's proxy thread may touch the HIP API while this
+                # thread captures: only this thread's calls are held to the capture rules then
+                mode = "thread_local" if engine.cfg.tp_size > 1 else "global"
+                with torch.cuda.graph(graph, pool=pool, stream=engine.stream, capture_error_mode=mode):
                     self.logits[:bs] = engine.model.forward(engine.ctx, batch)
             if pool is None:
                 pool = graph.pool()
