@@ -1,0 +1,81 @@
+"""CPU checks of host-side arithmetic the GPU path depends on: KV-pool sizing at 288 GB (BASELINE.json
+configs[4]), graph batch-size list, the benchmark workload generators (SURVEY.md 8d figures), the
+search space of the decode-batch GEMM kernel."""
+import random
+
+import torch
+
+GIB = 1 << 30
+
+
+def test_kv_pool_sizing_at_288gb_matches_survey_table():
+    """determine_num_pages = (memory_ratio * free - model_bytes) // bytes_per_page (P/engine/engine.py:148-168).
+    SURVEY.md section 8: KV bytes/token/rank 160 / 40 / 64 / 40 KiB; Llama-3.1-70B TP8 ~ 5.9 M tokens per rank."""
+    from mini_sglang_amd.engine import EngineConfig, determine_num_pages
+    from mini_sglang_amd.model import PRESETS
+
+    free = 288 * 10 ** 9  # what the part advertises; the formula is linear in it
+    cases = [  # model, tp, weight bytes per rank (SURVEY table, GiB), KV bytes per token per rank
+        ("qwen3-14b", 1, 27.5, 160 * 1024), ("qwen3-14b", 4, 6.9, 40 * 1024),
+        ("qwen3-32b", 4, 15.3, 64 * 1024), ("llama-3.1-70b", 8, 16.4, 40 * 1024),
+    ]
+    for name, tp, w_gib, kv_tok in cases:
+        for page in (1, 16, 256):
+            cfg = EngineConfig(model=PRESETS[name], tp_size=tp, page_size=page, memory_ratio=0.9)
+            w_bytes = int(w_gib * GIB)
+            pages = determine_num_pages(free, free - w_bytes, cfg)
+            assert pages == (int(0.9 * free) - w_bytes) // (kv_tok * page)
+    cfg = EngineConfig(model=PRESETS["llama-3.1-70b"], tp_size=8, page_size=1)
+    tokens = determine_num_pages(free, free - int(16.4 * GIB), cfg)
+    assert 5.8e6 < tokens < 6.0e6
+    cfg = EngineConfig(model=PRESETS["qwen3-14b"], tp_size=1, page_size=1, num_page_override=1234)
+    assert determine_num_pages(free, free, cfg) == 1234
+
+
+def test_graph_batch_sizes_match_reference_rule():
+    """P/engine/graph.py:49-67: [1, 2, 4] + range(8, max + 1, 8); max 256 above 80 GiB free, else 160."""
+    from mini_sglang_amd.engine import determine_graph_bs
+
+    assert determine_graph_bs(None, None, 200 * GIB) == [1, 2, 4] + list(range(8, 257, 8))
+    assert determine_graph_bs(None, None, 64 * GIB)[-1] == 160
+    assert determine_graph_bs(None, 20, 200 * GIB) == [1, 2, 4, 8, 16]
+    assert determine_graph_bs(None, 2, 200 * GIB) == [1, 2]
+    assert determine_graph_bs([3, 5], 256, 200 * GIB) == [3, 5]
+    assert determine_graph_bs(None, 0, 200 * GIB) == []
+
+
+def test_offline_benchmark_workload_matches_survey_figures():
+    """benchmark/offline/bench.py:11-31 replicated: random.seed(0); 256 x (ids, len 100..1024), then
+    256 x max_tokens 100..1024.  SURVEY.md 8d: sum in = 142 827, sum out = 133 966."""
+    random.seed(0)
+    prompts = [[random.randint(0, 10000) for _ in range(random.randint(100, 1024))] for _ in range(256)]
+    outs = [random.randint(100, 1024) for _ in range(256)]
+    assert sum(len(p) for p in prompts) == 142827 and sum(outs) == 133966
+    assert min(len(p) for p in prompts) == 107 and max(len(p) for p in prompts) == 1024
+
+
+def test_bench_contexts_are_the_token_weighted_distribution():
+    import bench
+
+    ctx = bench.bench_contexts(256)
+    assert ctx == bench.bench_contexts(256) and len(ctx) == 256
+    assert 100 <= min(ctx) and max(ctx) < 2048
+    assert 850 < sum(ctx) / 256 < 1000  # mean context per decoded token 902.8
+    assert len(bench.bench_contexts(8)) == 8
+
+
+def test_skinny_gemm_search_space_respects_kernel_limits():
+    """(k-slices, row tiles) offered by ops.skinny_candidates must satisfy csrc/gemm_skinny.hip's checks."""
+    from mini_sglang_amd import ops
+
+    for M in (1, 16, 17, 32, 33, 64):
+        mt = 1 if M <= 16 else 2 if M <= 32 else 4
+        for N, K in ((5120, 5120), (48, 64), (34816, 5120), (5120, 17408), (16, 128)):
+            cands = ops.skinny_candidates(M, N, K)
+            assert cands and len(set(cands)) == len(cands)
+            for sl, nt in cands:
+                assert N % (16 * nt) == 0 and 1 <= sl <= K // 64
+                assert sl <= (16 if mt * nt <= 2 else 8 if mt * nt <= 8 else 4)
+    assert not ops.skinny_supported(65, 5120, 5120) and not ops.skinny_supported(8, 40, 128)
+    assert not ops.skinny_supported(8, 48, 100) and ops.skinny_supported(64, 48, 64)
+    assert ops.linear.__doc__ and not ops._SKINNY_PLAN  # nothing is planned until skinny_tune ran on a GPU
