@@ -187,11 +187,14 @@ def main() -> None:
 
     mcfg = PRESETS[args.model]
     B = args.batch
+    # the latency-regime section is a single-GPU extra: under TP every additional graph is another capture
+    # with collectives inside, which the headline measurement does not need
+    small_batches = list(args.small_batches) if world == 1 else []
     contexts = bench_contexts(B)
     use_graph = os.environ.get("MSGL_BENCH_NO_GRAPH", "0") != "1"
     max_seq = 4096  # max_seq_len_override of the reference bench
     ecfg = EngineConfig(model=mcfg, dtype=torch.bfloat16, tp_rank=rank, tp_size=world, max_running_req=B,
-                        cuda_graph_bs=sorted(set([b for b in args.small_batches if b < B] + [B])) if use_graph else [],
+                        cuda_graph_bs=sorted(set([b for b in small_batches if b < B] + [B])) if use_graph else [],
                         page_size=args.page_size,
                         max_seq_len_override=max_seq, comm=comm, memory_ratio=0.9,
                         gemm_tune=os.environ.get("MSGL_GEMM_TUNE", "full"))
@@ -218,7 +221,7 @@ def main() -> None:
     rnd = random.Random(1234)
     prompts = [[rnd.randint(0, 10000) for _ in range(n)] for n in contexts]
     total_steps = args.steps + args.warmup
-    sp = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=total_steps + 8 + 13 * len(args.small_batches)) for _ in range(B)]
+    sp = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=total_steps + 8 + 13 * len(small_batches)) for _ in range(B)]
     states = [runner.add_request(p, s) for p, s in zip(prompts, sp)]
 
     # ---------------- prefill (untimed for `value`; yields TTFT) ----------------
@@ -298,7 +301,7 @@ def main() -> None:
     # ---------------- latency regime: the same model at small decode batches (not part of `value`) --------
     small = {}
     if use_graph:
-        for sb in [b for b in args.small_batches if b < B]:
+        for sb in [b for b in small_batches if b < B]:
             sub = running[:sb]
             for _ in range(3):
                 runner.decode_step(sub)
