@@ -228,6 +228,17 @@ int msgl_sample_from_logits(int32_t* out, const void* logits, const float* tempe
 int msgl_skinny_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
                         int64_t ldw, int64_t ldo, int dtype, int slices, int row_tiles, void* stream);
 
+/* Same product for mid-size decode batches (1 <= M <= 256; meant for 32 < M): the 8 waves of a workgroup
+ * stream different weight rows over the same k range and share the activation tile through LDS.
+ * N % (128 row_tiles) == 0, K % 64 == 0, ld* multiples of 8.  `row_tiles` (1, 2) and `k_splits`
+ * (1 .. K/64) are tuning knobs; with k_splits > 1 the caller provides
+ * msgl_wstream_gemm_workspace_bytes(M, N, k_splits) bytes of scratch (fp32 slabs, added in split order:
+ * deterministic).  No allocation, no sync. */
+int64_t msgl_wstream_gemm_workspace_bytes(int M, int N, int k_splits);
+int msgl_wstream_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
+                         int64_t ldw, int64_t ldo, int dtype, int row_tiles, int k_splits,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Tensor-parallel communicator over RCCL (libmsgl_comm.so).  Replaces
  * NCCLWrapper (C/src/pynccl.cu:72-175) / init_pynccl (P/kernel/pynccl.py:47-78).

@@ -35,6 +35,7 @@ HIP_SOURCES = [
     "attn_prefill.hip",
     "sampling.hip",
     "gemm_skinny.hip",
+    "gemm_wstream.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]
 GEMM_SOURCES = ["gemm.cpp"]

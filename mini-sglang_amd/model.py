@@ -185,6 +185,16 @@ class DenseDecoder:
                     if sk["used"]:
                         r["library_best_us"], r["best_us"] = r["best_us"], sk["skinny_us"]
                         r["kernel"] = f"msgl::skinny_gemm_kernel[slices {sk['slices']}, row tiles {sk['row_tiles']}]"
+                if 32 < bs <= ops.WSTREAM_MAX_M and name != "lm_head":  # LDS-shared weight-streaming kernel
+                    wsr = ops.wstream_tune(x, ws, r["best_us"])
+                    r.update(wstream_us=wsr["wstream_us"], wstream_row_tiles=wsr["row_tiles"],
+                             wstream_k_splits=wsr["k_splits"], wstream_used=wsr["used"])
+                    if wsr["used"]:
+                        r.setdefault("library_best_us", r["best_us"])
+                        r["best_us"] = wsr["wstream_us"]
+                        r["skinny_used"] = True  # reported as hand-written by bench.py
+                        r["kernel"] = (f"msgl::wstream_gemm_kernel[row tiles {wsr['row_tiles']}, "
+                                       f"k splits {wsr['k_splits']}]")
                 report.append(r)
                 if log is not None:
                     log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "

@@ -430,6 +430,86 @@ def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> 
     return res
 
 
+# ---- mid-size decode batches: LDS-shared activation tile (csrc/gemm_wstream.hip)
+_WSTREAM_PLAN: dict = {}  # (M, N, K, ldx, ldw, dtype code) -> (row tiles, k splits)
+WSTREAM_MAX_M = 256
+
+
+def wstream_supported(M: int, N: int, K: int) -> bool:
+    return 1 <= M <= WSTREAM_MAX_M and N % 128 == 0 and K % 64 == 0
+
+
+def wstream_linear(x: torch.Tensor, w: torch.Tensor, row_tiles: int, k_splits: int,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_wstream_gemm_nt (M <= 256); split-K scratch = the GEMM workspace."""
+    out, M, N, K = _gemm_args(x, w, out)
+    ws = gemm_workspace(x.device)
+    check(
+        lib().msgl_wstream_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                   out.stride(0), _dt(x), row_tiles, k_splits, ws.data_ptr(), ws.numel(), _stream()),
+        "wstream_gemm_nt",
+    )
+    return out
+
+
+def wstream_candidates(M: int, N: int, K: int):
+    """(row tiles, k splits) settings worth timing: enough workgroups to occupy the chip, scratch within the
+    GEMM workspace."""
+    out = []
+    for nt in (1, 2):
+        if N % (128 * nt):
+            continue
+        groups = N // (128 * nt)
+        for ks in (1, 2, 3, 4, 6, 8, 12, 16):
+            if ks > K // 64 or (ks > 1 and ks * M * N * 4 > GEMM_WORKSPACE_BYTES):
+                continue
+            if ks > 1 and groups * (ks // 2 if ks > 2 else 1) >= 1024:  # already far more workgroups than CUs
+                continue
+            out.append((nt, ks))
+    return out
+
+
+def wstream_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) -> dict:
+    """Time the LDS-shared weight-streaming kernel over (row tiles, k splits) on rotating weights and plan it for
+    this shape if it beats `incumbent_us` (the best of the library and the skinny kernel)."""
+    weights = list(weights)
+    w0 = weights[0]
+    M, K = x.shape
+    N = w0.shape[0]
+    res = dict(M=M, N=N, K=K, incumbent_us=incumbent_us, wstream_us=None, row_tiles=0, k_splits=0, used=False)
+    if not wstream_supported(M, N, K):
+        return res
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+
+    def time_us(nt, ks, rounds):
+        wstream_linear(x, w0, nt, ks, out)  # warm-up
+        ts = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(iters):
+                wstream_linear(x, weights[(i + 1) % len(weights)], nt, ks, out)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / iters)
+        return min(ts)
+
+    cands = wstream_candidates(M, N, K)
+    if not cands:
+        return res
+    ranked = sorted((time_us(nt, ks, 1), nt, ks) for nt, ks in cands)
+    best = min((time_us(nt, ks, 3), nt, ks) for _, nt, ks in ranked[:4])
+    res.update(wstream_us=best[0], row_tiles=best[1], k_splits=best[2], all={f"{nt}x{ks}": round(t, 1) for t, nt, ks in ranked})
+    key = (M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    if best[0] < incumbent_us:
+        _WSTREAM_PLAN[key] = (best[1], best[2])
+        _SKINNY_PLAN.pop(key, None)
+        res["used"] = True
+    else:
+        _WSTREAM_PLAN.pop(key, None)
+    return res
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M, N] = x[M, K] @ w[N, K]^T (the reference's `F.linear`, P/layers/linear.py:32): the hand-written
     weight-streaming kernel where skinny_tune() planned it (decode batches <= 64), else msgl_gemm_nt with the
@@ -437,6 +517,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     out, M, N, K = _gemm_args(x, w, out)
     if M == 0:
         return out
+    if M <= WSTREAM_MAX_M and _WSTREAM_PLAN:
+        plan = _WSTREAM_PLAN.get((M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return wstream_linear(x, w, plan[0], plan[1], out)
     if M <= SKINNY_MAX_M and _SKINNY_PLAN:
         plan = _SKINNY_PLAN.get((M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:

@@ -149,3 +149,49 @@ def test_skinny_tune_plans_only_when_faster_and_linear_dispatches(ops, dev):
     print(f"down-proj M=8: library {lib['best_us']:.1f} us, skinny {rep['skinny_us']:.1f} us "
           f"(slices {rep['slices']}, row tiles {rep['row_tiles']})")
     ops._SKINNY_PLAN.pop(key, None)
+
+
+# ---------------------------------------------------------------- LDS-shared weight-streaming kernel (M <= 256)
+@pytest.mark.parametrize("M", [33, 64, 65, 100, 128, 129, 200, 256])
+@pytest.mark.parametrize("N,K", [(5120, 5120), (7168, 5120), (256, 128), (1024, 17408), (2304, 640)])
+def test_wstream_gemm_matches_fp32_reference(ops, dev, M, N, K):
+    """All (row tiles, k splits) settings incl. ragged splits; the three tile heights (M <= 64, 128, 256) and
+    padded rows; split-K slabs are added in a fixed order => bitwise repeatable."""
+    g = torch.Generator(device=dev).manual_seed(M * 17 + N + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    ref = _ref(x, w)
+    assert ops.wstream_supported(M, N, K)
+    cands = ops.wstream_candidates(M, N, K)
+    assert cands
+    for nt, ks in cands + [(1, min(5, K // 64))]:
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.wstream_linear(x, w, nt, ks, out)
+        _check(out, ref)
+        assert torch.equal(out, ops.wstream_linear(x, w, nt, ks))
+
+
+def test_wstream_gemm_small_m_fp16_and_strides(ops, dev):
+    g = torch.Generator(device=dev).manual_seed(7)
+    big = (torch.randn((40, 3 * 512), generator=g, device=dev) * 0.5).to(torch.float16)
+    x = big[:, 512:1024]
+    w_all = (torch.randn((768, 1024), generator=g, device=dev) * 0.05).to(torch.float16)
+    w = w_all[:, :512]
+    fused = torch.zeros((40, 2048), dtype=torch.float16, device=dev)
+    for nt, ks in ((1, 1), (2, 2), (1, 4)):
+        out = ops.wstream_linear(x, w, nt, ks, out=fused[:, 256:1024])
+        _check(out, _ref(x, w))
+    assert fused[:, :256].abs().max().item() == 0 and fused[:, 1024:].abs().max().item() == 0
+    x1 = x[:1]
+    _check(ops.wstream_linear(x1, w, 1, 2), _ref(x1, w))  # M = 1: 63 padded rows
+
+
+def test_wstream_gemm_rejects_what_it_cannot_do(ops, dev):
+    x = torch.zeros((64, 256), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.wstream_linear(x, torch.zeros((192, 256), dtype=torch.bfloat16, device=dev), 1, 1)  # N % 128
+    w = torch.zeros((256, 256), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.wstream_linear(x, w, 1, 5)  # more splits than 64-k steps
+    with pytest.raises(RuntimeError):
+        ops.wstream_linear(torch.zeros((257, 256), dtype=torch.bfloat16, device=dev), w, 1, 1)

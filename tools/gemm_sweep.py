@@ -54,6 +54,10 @@ def main():
                 sk = ops.skinny_tune(x, ws, r["best_us"], iters=10)
                 r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
                          skinny_used=sk["used"])
+            if 32 < bs <= ops.WSTREAM_MAX_M:
+                wsr = ops.wstream_tune(x, ws, min(r["best_us"], r.get("skinny_us") or 1e30), iters=10)
+                r.update(wstream_us=wsr["wstream_us"], wstream_row_tiles=wsr["row_tiles"],
+                         wstream_k_splits=wsr["k_splits"], wstream_used=wsr["used"], wstream_all=wsr.get("all"))
             got = ops.linear(x, ws[0]).float()
             ref = x.float() @ ws[0].float().t()
             err = (got - ref).abs().max().item()
@@ -64,7 +68,11 @@ def main():
                      default_tbps=wbytes / r["default_us"] / 1e6, best_tbps=wbytes / r["best_us"] / 1e6)
             rows.append(r)
             tot_def += r["default_us"] * per_step[name]
-            eff = min(r["best_us"], r.get("skinny_us") or 1e30)
+            eff = min(r["best_us"], r.get("skinny_us") or 1e30, r.get("wstream_us") or 1e30)
+            if r.get("wstream_us"):
+                print(f"      wstream: {r['wstream_us']:8.1f} us ({wbytes / r['wstream_us'] / 1e6:.2f} TB/s) row tiles "
+                      f"{r['wstream_row_tiles']} k splits {r['wstream_k_splits']}  {'<< used' if r['wstream_used'] else ''}"
+                      f"  {r['wstream_all']}", flush=True)
             tot_best += eff * per_step[name]
             if r.get("skinny_us"):
                 print(f"      skinny: {r['skinny_us']:8.1f} us ({wbytes / r['skinny_us'] / 1e6:.2f} TB/s) slices "
