@@ -363,6 +363,10 @@ def _gemm_args(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]):
 # shapes where skinny_tune() measured it faster than the library's best solution
 _SKINNY_PLAN: dict = {}
 SKINNY_MAX_M = 64
+# a hand-written kernel replaces the library's pick only when the isolated timing says it is clearly faster:
+# inside the captured step (other kernels' tails, cache state) a 1-3 % edge measured back to back does not
+# survive (M = 256 qkv / o: 37.7 + 6.5 us reduce vs 39 / 46 us library, step time unchanged)
+PLAN_MARGIN = 0.95
 
 
 def skinny_supported(M: int, N: int, K: int) -> bool:
@@ -422,7 +426,7 @@ def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> 
     best = min((time_us(sl, nt, 3), sl, nt) for _, sl, nt in ranked[:4])  # re-time the best few
     res.update(skinny_us=best[0], slices=best[1], row_tiles=best[2])
     key = (M, N, K, x.stride(0), w0.stride(0), _dt(x))
-    if best[0] < library_us:
+    if best[0] < PLAN_MARGIN * library_us:
         _SKINNY_PLAN[key] = (best[1], best[2])
         res["used"] = True
     else:
@@ -501,7 +505,7 @@ def wstream_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) 
     best = min((time_us(nt, ks, 3), nt, ks) for _, nt, ks in ranked[:4])
     res.update(wstream_us=best[0], row_tiles=best[1], k_splits=best[2], all={f"{nt}x{ks}": round(t, 1) for t, nt, ks in ranked})
     key = (M, N, K, x.stride(0), w0.stride(0), _dt(x))
-    if best[0] < incumbent_us:
+    if best[0] < PLAN_MARGIN * incumbent_us:
         _WSTREAM_PLAN[key] = (best[1], best[2])
         _SKINNY_PLAN.pop(key, None)
         res["used"] = True
