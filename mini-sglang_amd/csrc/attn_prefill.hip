@@ -60,7 +60,6 @@ struct PrefillParams {
   uint16_t* out;
   int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
   int batch, hq, group;
-  int tr_variant;  // bring-up switch (MSGL_TR_VARIANT): 1 = lane j of a tr-read passes row j & 3, chunk j >> 2
   float scale_log2;
 };
 
@@ -368,8 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
   int voff[4];
   {
     const int j = lane & 15;
-    const int r4 = p.tr_variant ? (j & 3) : (j >> 2);
-    const int ch = p.tr_variant ? (j >> 2) : (j & 3);
+    const int r4 = j >> 2;  // lane j of a 16-lane tr-read group passes row j >> 2, 8-byte chunk j & 3
+    const int ch = j & 3;   // (layout confirmed on hardware by tools/tr_probe.hip, pattern 1)
     const int w = (16 * ((lane >> 4) & 1) + 4 * ch) * 2;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) voff[nb] = kTileBytes + hi * 1024 + r4 * 256 + (((nb ^ r4) & 3) << 6) + w;
@@ -492,16 +491,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
 
 using namespace msgl;
 
-// MSGL_PREFILL_IMPL=1|2 overrides the default kernel generation (A/B runs); read once.
-static int default_prefill_impl() {
-  static int cached = 0;
-  if (cached == 0) {
-    const char* e = getenv("MSGL_PREFILL_IMPL");
-    cached = (e && e[0] == '1') ? 1 : 2;
-  }
-  return cached;
-}
-
 extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
                                  const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
                                  const int32_t* seq_lens, const int32_t* cu_seqlens_q, const int32_t* tile_cu,
@@ -542,17 +531,13 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
   p.batch = batch;
   p.hq = num_q_heads;
   p.group = num_q_heads / num_kv_heads;
-  {
-    static const char* e = getenv("MSGL_TR_VARIANT");
-    p.tr_variant = (e && e[0] == '1') ? 1 : 0;
-  }
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != MSGL_BF16 && dtype != MSGL_FP16) {
     set_error("attn_prefill: unsupported dtype code %d", dtype);
     return MSGL_EINVAL;
   }
-  if (impl == 0) impl = default_prefill_impl();
+  if (impl == 0) impl = 2;  // the tr-read kernel; impl 1 keeps the first-generation kernel callable (cross-check in tests)
   if (impl == 1) {  // first-generation kernel: 2-D grid in natural order (tile_order unused)
     const dim3 grid((unsigned)total_tiles, (unsigned)num_q_heads), block(256);
     if (dtype == MSGL_BF16) attn_prefill_kernel<BF16><<<grid, block, 0, s>>>(p);
