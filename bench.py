@@ -175,6 +175,10 @@ def main() -> None:
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node: rendezvous and the RCCL bootstrap over loopback (the box's hostname may not resolve);
+        # the data path is xGMI peer-to-peer either way
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         from mini_sglang_amd.kernel import init_pynccl
 

@@ -64,6 +64,8 @@ struct msgl_comm {
   void* buf = nullptr;       // staging buffer (device)
   void* reg_handle = nullptr;  // ncclCommRegister handle, may stay null
   bool stage = false;          // MSGL_COMM_STAGE=1
+  bool shortcut1 = true;       // world == 1: skip the library call (MSGL_COMM_NO_SHORTCUT=1 keeps it, so that
+                               // a 1-GPU box can exercise RCCL's enqueue path, e.g. under hipGraph capture)
 };
 
 extern "C" {
@@ -98,6 +100,8 @@ int msgl_comm_create(msgl_comm_t* out, int rank, int world_size, const char id[M
   }
   const char* st = getenv("MSGL_COMM_STAGE");
   c->stage = st && st[0] == '1';
+  const char* ns = getenv("MSGL_COMM_NO_SHORTCUT");
+  c->shortcut1 = !(ns && ns[0] == '1');
   if (max_bytes > 0) {
     if (hipMalloc(&c->buf, max_bytes) != hipSuccess) {
       (void)hipGetLastError();
@@ -115,7 +119,7 @@ int msgl_comm_all_reduce_sum(msgl_comm_t c, void* data, size_t count, int dtype,
   if (!c || !data) { set_err("comm_all_reduce: null pointer"); return MSGL_EINVAL; }
   ncclDataType_t dt;
   if (!to_nccl_dtype(dtype, &dt)) { set_err("comm_all_reduce: dtype code %d unsupported", dtype); return MSGL_EINVAL; }
-  if (count == 0 || c->world == 1) return MSGL_OK;
+  if (count == 0 || (c->world == 1 && c->shortcut1)) return MSGL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = count * 2;
   if (c->stage && c->buf && c->reg_handle && bytes <= c->max_bytes && data != c->buf) {
@@ -134,7 +138,7 @@ int msgl_comm_all_gather(msgl_comm_t c, void* dst, const void* src, size_t count
   if (!to_nccl_dtype(dtype, &dt)) { set_err("comm_all_gather: dtype code %d unsupported", dtype); return MSGL_EINVAL; }
   if (count == 0) return MSGL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (c->world == 1) {
+  if (c->world == 1 && c->shortcut1) {
     if (dst != src) COMM_HIP(hipMemcpyAsync(dst, src, count * 2, hipMemcpyDeviceToDevice, s), "all_gather copy");
     return MSGL_OK;
   }
