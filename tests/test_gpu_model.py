@@ -203,3 +203,54 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
     for li in (0, m.num_layers // 2, m.num_layers - 1):  # one bf16 ulp of a K element of magnitude 4 is 3e-2
         torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=tol, rtol=tol)
     eng.shutdown()
+
+
+class _OneGpuTpComm:
+    """Stands in for rank 0's RCCL communicator of a tp-rank group on a box with ONE GPU: collectives go through
+    a one-rank RCCL communicator (world-1 shortcut disabled, so they are real ncclAllReduce / ncclAllGather
+    enqueues), the all-gather fills shard 0 of the destination and zeroes the others.  Numerically that is
+    'every other rank contributed zeros' -- enough to run the engine's TP code path end to end."""
+
+    def __init__(self, tp_size):
+        from mini_sglang_amd import kernel
+
+        self.tp_size = tp_size
+        self.inner = kernel.RcclCommunicator(0, 1, 0, kernel.create_unique_id())
+
+    def all_reduce(self, x, op="sum"):
+        self.inner.all_reduce(x, op)
+
+    def all_gather(self, out, x):
+        rows = x.shape[0]
+        self.inner.all_gather(out[:rows], x)
+        out[rows:].zero_()
+
+    def destroy(self):
+        self.inner.destroy()
+
+
+@pytest.mark.parametrize("tp", [2])
+def test_tp_code_path_runs_on_one_gpu_with_collectives_in_the_graph(dev, tp, monkeypatch):
+    """Engine(tp_size=2, tp_rank=0): sharded weights and KV pool (5 q heads / 1 kv head per rank), masked
+    vocab-parallel gather, row-parallel all-reduces and the LM-head all-gather captured inside the decode
+    hipGraph (thread-local capture mode), GEMM search on the shard shapes.  Graph replay must equal eager."""
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.model import PRESETS
+
+    monkeypatch.setenv("MSGL_COMM_NO_SHORTCUT", "1")
+    outs = []
+    for graphs in (True, False):
+        comm = _OneGpuTpComm(tp)
+        cfg = EngineConfig(model=PRESETS["tiny"], dtype=torch.bfloat16, tp_rank=0, tp_size=tp, max_running_req=8,
+                           page_size=16, cuda_graph_bs=[1, 2, 4] if graphs else [], max_seq_len_override=256,
+                           num_page_override=64, comm=comm, seed=7)
+        eng = Engine(cfg, dev)
+        assert eng.model.hq == 5 and eng.model.hkv == 1 and eng.attn_backend.kv_heads == 1
+        assert eng.model.lm_head.shape[0] == (PRESETS["tiny"].vocab_size + tp - 1) // tp
+        ids, stats, _ = run(eng, prompts(3), 6)
+        assert stats["decode_steps"] == 5 and all(len(i) == 6 for i in ids)
+        assert all(0 <= t < PRESETS["tiny"].vocab_size for seq in ids for t in seq)
+        outs.append(ids)
+        eng.shutdown()
+        comm.destroy()
+    assert outs[0] == outs[1]
