@@ -7,7 +7,7 @@
 // walk the SAME k range over DIFFERENT weight rows, so the activation tile of a step is staged once per
 // workgroup in LDS and read by all 8 waves as the B operand:
 //   * workgroup = 8 waves x NT row tiles x 16 rows; step = 64 k; x tile [16 MT rows][64 k] double-buffered
-//     in LDS, row pitch 144 B (the 16 rows a B-fragment read touches fall into 16 disjoint bank groups);
+//     in LDS, 128-B rows with the 16-B chunks XOR-swizzled by the row (conflict-free reads and writes, measured);
 //     x goes global -> VGPR -> LDS, requested one step ahead and written after the step's MFMAs;
 //   * each wave keeps the weight fragments of the next three steps in flight (a ring of four register sets,
 //     NT x 2 loads of 16 B per lane per step); one barrier per step;
@@ -37,7 +37,7 @@ __device__ __forceinline__ ws_f32x4 ws_mfma16(const WS4& a, const WS4& b, const 
 
 constexpr int kWsWaves = 8;
 constexpr int kWsStepK = 64;                     // k per step
-constexpr int kWsPitch = kWsStepK * 2 + 16;      // LDS row pitch in bytes (144: 16 rows -> 16 disjoint bank groups)
+constexpr int kWsPitch = kWsStepK * 2;           // LDS row pitch in bytes (128); 16-B chunk c of row r sits at c ^ (r & 7)
 
 // MT = 16-token column tiles (M <= 16 MT; 4, 8 or 16), NT = 16-row weight tiles per wave (1 or 2).
 // PARTIAL: write fp32 slabs part[blockIdx.y][M][N] instead of the rounded output.
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * kWsWaves) void wstream_gemm_kernel(
     const int q = tid + p * (64 * kWsWaves);
     const int row = q / (kWsStepK / 8), c = q % (kWsStepK / 8);
     xg[p] = x + (int64_t)min(row, M - 1) * ldx + c * 8;
-    xl[p] = row * kWsPitch + c * 16;
+    xl[p] = row * kWsPitch + ((c ^ (row & 7)) * 16);  // XOR swizzle: see compute()
   }
 
   ws_f32x4 acc[NT][MT];
@@ -98,13 +98,18 @@ __global__ __launch_bounds__(64 * kWsWaves) void wstream_gemm_kernel(
 #pragma unroll
     for (int p = 0; p < kPerThread; ++p) *reinterpret_cast<WS4*>(xs + buf * kTileBytes + xl[p]) = xr.v[p];
   };
+  // B fragment of (column tile t, k32 group j): lane (r, kg) reads 16 B of row 16 t + r, chunk 4 j + kg, stored at
+  // chunk position (4 j + kg) ^ (r & 7).  Measured with tools/lds_probe.hip: this layout reads and writes at
+  // the conflict-free rate; a padded 144-B pitch costs +50 % on the reads (PMC: 44 % of the LDS cycles of the
+  // first version were bank-conflict cycles) because the LDS services lanes of two k-groups in the same cycle.
+  const int sw0 = ((kg ^ (r & 7)) * 16), sw1 = (((4 + kg) ^ (r & 7)) * 16);
   auto compute = [&](const Frag& f, int buf) {
-    const unsigned char* base = xs + buf * kTileBytes + r * kWsPitch + kg * 16;
+    const unsigned char* base = xs + buf * kTileBytes + r * kWsPitch;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const WS4 b = *reinterpret_cast<const WS4*>(base + t * 16 * kWsPitch + j * 64);
+        const WS4 b = *reinterpret_cast<const WS4*>(base + t * 16 * kWsPitch + (j ? sw1 : sw0));
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[i][t] = ws_mfma16<T>(f.a[i][j], b, acc[i][t]);
       }
