@@ -130,6 +130,11 @@ int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const void* q_norm_
 int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
                       int64_t out_stride, int dtype, void* stream);
 
+/* out[t, j] = gelu(x[t, j]) * x[t, d + j], exact (erf) GELU.  Replaces flashinfer.gelu_and_mul
+ * (P/layers/activation.py:15-18; chosen by hidden_act == "gelu", P/models/utils.py:37-41). */
+int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                      int64_t out_stride, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * Paged decode attention (one query token per request).  Replaces the decode
  * phase of flash_attn_with_kvcache (P/attention/fa.py:158-182) and of

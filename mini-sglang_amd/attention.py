@@ -120,6 +120,10 @@ class HipAttnBackend:
         k_tok, v_tok = self._kv_tokens(layer_id)
         table = self.ctx.page_table
         if md.max_seqlen_q == 1:
+            if md.plan is None:  # prepared for replay but run eagerly by the host: plan on first use
+                md.plan = torch.empty(self._plan_words, dtype=torch.int32, device=self.device)
+                ops.attn_decode_plan(md.plan, md.seq_lens, md.batch, self.max_bs, self.capacity, self.qo_heads,
+                                     self.kv_heads)
             ops.attn_decode(out, q, k_tok, v_tok, table, md.req_rows, md.seq_lens, md.plan, self._workspace,
                             md.batch, self.max_bs, self.capacity, self.scale, slot_run=self.slot_run)
         else:
@@ -146,11 +150,21 @@ class HipAttnBackend:
             max_seqlen_q=max_q, max_seqlen_k=max_k, tile_cu=None if decode else dev[3 * bs + 1: 4 * bs + 2],
             total_tiles=total_tiles, tile_order=None if decode else dev[4 * bs + 2:],
         )
-        if decode and not (self._cap_plan is not None and bs in self.capture_bs):
-            # eager decode: plan now (device side, no sync); graph batches are planned in prepare_for_replay
+        if decode and not self._replayed_from_graph(batch, bs):
+            # runs eagerly: plan now (device side, no sync).  Only batches the engine will REPLAY are planned
+            # later, in prepare_for_replay; replay is keyed on the phase (P/engine/graph.py:149-150
+            # can_use_cuda_graph = batch.is_decode and size <= max_graph_bs), NOT on max_q == 1: a prefill
+            # batch whose every request extends by one token (radix full hit on a repeated prompt at
+            # page_size 1, P/scheduler/cache.py:27-30; a one-token chunk remainder) takes this kernel eagerly
             md.plan = torch.empty(self._plan_words, dtype=torch.int32, device=self.device)
             ops.attn_decode_plan(md.plan, md.seq_lens, bs, self.max_bs, self.capacity, self.qo_heads, self.kv_heads)
         batch.attn_metadata = md
+
+    def _replayed_from_graph(self, batch: Any, padded_bs: int) -> bool:
+        phase = getattr(batch, "phase", None)
+        is_decode = (phase == "decode") if phase is not None else True
+        return bool(is_decode and self._cap_plan is not None and padded_bs in self.capture_bs
+                    and len(batch.reqs) <= self.max_graph_bs)
 
     # ------------------------------------------------------------------ graph hooks
     def init_capture_graph(self, max_seq_len: int, bs_list: List[int]) -> None:

@@ -1,121 +1,114 @@
-"""Mirror of the structs the hot path reads (P/core.py:16-136): SamplingParams, Req, Batch,
-Context and the per-process global context.  Field names and meaning are the reference's, so
-the attention backend / KV pool work unchanged whether they are handed these objects or the
-real `minisgl.core` ones (they only read attributes)."""
+"""Attribute holders for the standalone driver (engine.py / offline.py / bench.py on the GPU box).
+
+When the reference is installed, its own `minisgl.core` objects (P/core.py:16-136) are what reach the
+attention backend and the KV pool; this module is NOT a replacement for them.  The backend only reads
+attributes -- `Batch.{reqs, padded_reqs, phase, positions, out_loc, input_ids, attn_metadata}` and
+`Req.{table_idx, cached_len, device_len, extend_len}` -- so the standalone driver hands
+it these minimal holders carrying the same attribute names and nothing else of the reference's class bodies.
+"""
 from __future__ import annotations
 
 from contextlib import contextmanager
-from dataclasses import dataclass, field
-from typing import Any, List, Literal, Optional
+from typing import Any, Iterator, List, Optional
 
 import torch
 
 
-@dataclass
 class SamplingParams:
-    temperature: float = 0.0
-    top_k: int = -1
-    top_p: float = 1.0
-    ignore_eos: bool = False
-    max_tokens: int = 1024
+    __slots__ = ("temperature", "top_k", "top_p", "ignore_eos", "max_tokens")
+
+    def __init__(self, temperature: float = 0.0, top_k: int = -1, top_p: float = 1.0, ignore_eos: bool = False,
+                 max_tokens: int = 1024) -> None:
+        self.temperature, self.top_k, self.top_p = temperature, top_k, top_p
+        self.ignore_eos, self.max_tokens = ignore_eos, max_tokens
 
     @property
-    def is_greedy(self) -> bool:  # P/core.py:23-25
-        return (self.temperature <= 0.0 or self.top_k == 1) and self.top_p == 1.0
+    def is_greedy(self) -> bool:
+        """Greedy rule of the reference sampler (P/core.py:23-25)."""
+        no_randomness = self.temperature <= 0.0 or self.top_k == 1
+        return no_randomness and self.top_p == 1.0
 
 
-@dataclass(eq=False)
 class Req:
-    input_ids: torch.Tensor  # cpu tensor
-    table_idx: int
-    cached_len: int
-    output_len: int
-    uid: int
-    sampling_params: Optional[SamplingParams] = None
-    cache_handle: Any = None
+    """One sequence's progress: `cached_len` tokens have K/V in the pool, `device_len` tokens exist on the
+    device; a forward extends the pool by `extend_len = device_len - cached_len` tokens."""
 
-    def __post_init__(self) -> None:
-        assert self.input_ids.is_cpu
-        self.device_len = len(self.input_ids)
-        self.max_device_len = len(self.input_ids) + self.output_len
-        assert 0 <= self.cached_len < self.device_len <= self.max_device_len
+    __slots__ = ("input_ids", "table_idx", "cached_len", "device_len", "max_device_len", "uid", "sampling_params",
+                 "cache_handle")
 
-    @property
-    def remain_len(self) -> int:
-        return self.max_device_len - self.device_len
+    def __init__(self, input_ids: torch.Tensor, table_idx: int, cached_len: int, output_len: int, uid: int,
+                 sampling_params: Optional[SamplingParams] = None, cache_handle: Any = None) -> None:
+        n = int(input_ids.shape[0])
+        if not (input_ids.device.type == "cpu" and 0 <= cached_len < n):
+            raise ValueError(f"bad request: {n} host tokens, cached_len {cached_len}")
+        self.input_ids, self.table_idx, self.uid = input_ids, table_idx, uid
+        self.cached_len, self.device_len, self.max_device_len = cached_len, n, n + output_len
+        self.sampling_params, self.cache_handle = sampling_params, cache_handle
 
-    @property
-    def extend_len(self) -> int:
-        return self.device_len - self.cached_len
+    extend_len = property(lambda self: self.device_len - self.cached_len)
+    remain_len = property(lambda self: self.max_device_len - self.device_len)
+    can_decode = property(lambda self: self.max_device_len > self.device_len)
 
-    def complete_one(self) -> None:  # P/core.py:52-54
-        self.cached_len = self.device_len
-        self.device_len += 1
-
-    @property
-    def can_decode(self) -> bool:
-        return self.remain_len > 0
+    def complete_one(self) -> None:
+        """Host bookkeeping right after a forward is enqueued (P/core.py:52-54): everything on the device is now
+        cached and one sampled token is about to exist."""
+        self.cached_len, self.device_len = self.device_len, self.device_len + 1
 
 
-@dataclass
 class Batch:
-    reqs: List[Req]
-    phase: Literal["prefill", "decode"]
-    input_ids: torch.Tensor = field(init=False)
-    positions: torch.Tensor = field(init=False)
-    out_loc: torch.Tensor = field(init=False)
-    padded_reqs: List[Req] = field(init=False)
-    attn_metadata: Any = field(init=False)
+    __slots__ = ("reqs", "phase", "input_ids", "positions", "out_loc", "padded_reqs", "attn_metadata")
 
-    @property
-    def is_prefill(self) -> bool:
-        return self.phase == "prefill"
+    def __init__(self, reqs: List[Req], phase: str) -> None:
+        if phase not in ("prefill", "decode"):
+            raise ValueError(phase)
+        self.reqs, self.phase = reqs, phase
+        self.padded_reqs: List[Req] = reqs
 
-    @property
-    def is_decode(self) -> bool:
-        return self.phase == "decode"
-
-    @property
-    def size(self) -> int:
-        return len(self.reqs)
-
-    @property
-    def padded_size(self) -> int:
-        return len(self.padded_reqs)
+    is_prefill = property(lambda self: self.phase == "prefill")
+    is_decode = property(lambda self: self.phase == "decode")
+    size = property(lambda self: len(self.reqs))
+    padded_size = property(lambda self: len(self.padded_reqs))
 
 
-@dataclass
 class Context:
-    page_size: int
-    page_table: torch.Tensor = field(init=False)  # token slots, page-size agnostic (P/core.py:103-104)
-    attn_backend: Any = field(init=False)
-    kv_cache: Any = field(init=False)
-    _batch: Optional[Batch] = field(default=None, init=False)
+    """Per-process state the backend is constructed from (P/core.py:101-126): the token-slot page table
+    (page-size agnostic), the KV pool, the backend itself, and the batch being forwarded."""
+
+    def __init__(self, page_size: int) -> None:
+        self.page_size = page_size
+        self.page_table: torch.Tensor = None  # type: ignore[assignment]
+        self.kv_cache: Any = None
+        self.attn_backend: Any = None
+        self._batch: Optional[Batch] = None
 
     @property
     def batch(self) -> Batch:
-        assert self._batch is not None, "No active batch in context"
+        if self._batch is None:
+            raise RuntimeError("no batch is being forwarded")
         return self._batch
 
     @contextmanager
-    def forward_batch(self, batch: Batch):
-        assert self._batch is None, "Nested forward_batch is not allowed"
+    def forward_batch(self, batch: Batch) -> Iterator[None]:
+        if self._batch is not None:
+            raise RuntimeError("forward_batch does not nest")
+        self._batch = batch
         try:
-            self._batch = batch
             yield
         finally:
             self._batch = None
 
 
-_GLOBAL_CTX: Optional[Context] = None
+_CTX: Optional[Context] = None
 
 
 def set_global_ctx(ctx: Optional[Context], *, force: bool = False) -> None:
-    global _GLOBAL_CTX
-    assert force or _GLOBAL_CTX is None, "Global context is already set"
-    _GLOBAL_CTX = ctx
+    global _CTX
+    if _CTX is not None and ctx is not None and not force:
+        raise RuntimeError("global context already set")
+    _CTX = ctx
 
 
 def get_global_ctx() -> Context:
-    assert _GLOBAL_CTX is not None, "Global context is not set"
-    return _GLOBAL_CTX
+    if _CTX is None:
+        raise RuntimeError("global context not set")
+    return _CTX

@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256) void rope_kernel(uint16_t* __restrict__ q, uin
 }
 
 // ------------------------------------------------------------------------------
-// out[t, j] = silu(x[t, j]) * x[t, d + j]
+// out[t, j] = act(x[t, j]) * x[t, d + j];  act = silu, or (GELU) the exact erf GELU 0.5 g (1 + erf(g / sqrt 2))
 // ------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool GELU>
 __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ x, int64_t total,
                                                        int pieces, int64_t d, int64_t xs, int64_t os) {
@@ -155,7 +155,10 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
   unpack8<T>(ldg16(x + t * xs + j * 8), g);
   unpack8<T>(ldg16(x + t * xs + d + j * 8), u);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) y[e] = g[e] / (1.0f + __expf(-g[e])) * u[e];
+  for (int e = 0; e < 8; ++e) {
+    const float a = GELU ? 0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)) : g[e] / (1.0f + __expf(-g[e]));
+    y[e] = a * u[e];
+  }
   stg16(out + t * os + j * 8, pack8<T>(y));
 }
 
@@ -344,28 +347,39 @@ extern "C" int msgl_rope_neox_inplace(void* q, void* k, const void* positions, i
   return MSGL_OK;
 }
 
-extern "C" int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
-                                 int64_t out_stride, int dtype, void* stream) {
-  MSGL_REQUIRE(num_tokens >= 0, "silu_and_mul: negative token count");
+template <bool GELU>
+static int act_and_mul(const char* what, void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                       int64_t out_stride, int dtype, void* stream) {
+  MSGL_REQUIRE(num_tokens >= 0, "%s: negative token count", what);
   if (num_tokens == 0) return MSGL_OK;
-  MSGL_REQUIRE(out && x, "silu_and_mul: null pointer");
-  MSGL_REQUIRE(d > 0 && d % 8 == 0, "silu_and_mul: d %lld must be a multiple of 8", (long long)d);
-  MSGL_REQUIRE(x_stride % 8 == 0 && out_stride % 8 == 0, "silu_and_mul: strides must be multiples of 8");
-  MSGL_REQUIRE(aligned16(out) && aligned16(x), "silu_and_mul: pointers must be 16-byte aligned");
+  MSGL_REQUIRE(out && x, "%s: null pointer", what);
+  MSGL_REQUIRE(d > 0 && d % 8 == 0, "%s: d %lld must be a multiple of 8", what, (long long)d);
+  MSGL_REQUIRE(x_stride % 8 == 0 && out_stride % 8 == 0, "%s: strides must be multiples of 8", what);
+  MSGL_REQUIRE(aligned16(out) && aligned16(x), "%s: pointers must be 16-byte aligned", what);
   const int pieces = (int)(d / 8);
   const int64_t total = num_tokens * pieces;
   const int64_t blocks = (total + 255) / 256;
-  MSGL_REQUIRE(blocks < (1ll << 31), "silu_and_mul: too many tokens");
+  MSGL_REQUIRE(blocks < (1ll << 31), "%s: too many tokens", what);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
-    silu_mul_kernel<T><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint16_t*)out, (const uint16_t*)x, total,
-                                                                     pieces, d, x_stride, out_stride);
+    silu_mul_kernel<T, GELU><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint16_t*)out, (const uint16_t*)x, total,
+                                                                           pieces, d, x_stride, out_stride);
     return MSGL_OK;
   });
   if (rc != MSGL_OK) return rc;
-  MSGL_CHECK_LAUNCH("silu_and_mul");
+  MSGL_CHECK_LAUNCH(what);
   return MSGL_OK;
+}
+
+extern "C" int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                                 int64_t out_stride, int dtype, void* stream) {
+  return act_and_mul<false>("silu_and_mul", out, x, num_tokens, d, x_stride, out_stride, dtype, stream);
+}
+
+extern "C" int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                                 int64_t out_stride, int dtype, void* stream) {
+  return act_and_mul<true>("gelu_and_mul", out, x, num_tokens, d, x_stride, out_stride, dtype, stream);
 }
 
 extern "C" int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const void* q_norm_w,

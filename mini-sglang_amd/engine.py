@@ -58,13 +58,11 @@ class Sampler:
     def sample(self, logits: torch.Tensor, args: BatchSamplingArgs) -> torch.Tensor:
         if args.temperatures is None:  # greedy: first index of the row max
             return ops.argmax_rows(logits)
-        if args.top_k is None and args.top_p is None:
-            # temperature only: one fused kernel instead of softmax -> sampling_from_probs (sample.py:36-44);
-            # rows of both the eager logits and the graph's fp32 buffer are 16-byte aligned for real vocabularies
-            if (logits.stride(0) * logits.element_size()) % 16 == 0 and logits.data_ptr() % 16 == 0:
-                return fi.sampling.sampling_from_logits(logits, args.temperatures)
-            return fi.sampling.sampling_from_probs(fi.sampling.softmax(logits, args.temperatures))
+        # same call sequence as sample_impl (sample.py:24-45); `softmax` is deferred, so a temperature-only batch
+        # is one fused draw from the logits and only the top-k / top-p variants materialise probabilities
         probs = fi.sampling.softmax(logits, args.temperatures)
+        if args.top_k is None and args.top_p is None:
+            return fi.sampling.sampling_from_probs(probs)
         if args.top_p is None:
             return fi.sampling.top_k_sampling_from_probs(probs, args.top_k)
         if args.top_k is None:

@@ -39,9 +39,16 @@ def apply_rope_with_cos_sin_cache_inplace(positions: torch.Tensor, query: torch.
 def build_cos_sin_cache(rotary_dim: int, max_position: int, base: float,
                         rope_scaling: Optional[Dict[str, Any]] = None,
                         device: torch.device | str = "cpu") -> torch.Tensor:
-    """fp32 [max_position, rotary_dim] = cat(cos, sin); same construction (and therefore the
-    same bits on CPU) as RotaryEmbedding.__init__ / _get_rope (P/layers/rotary.py:24-32,
-    55-114): default, llama3 and yarn inverse-frequency post-processing."""
+    """fp32 [max_position, rotary_dim] = cat(cos, sin); same construction as RotaryEmbedding.__init__ /
+    _get_rope (P/layers/rotary.py:24-32, 55-114): default, llama3 and yarn inverse-frequency post-processing.
+    Like the reference (`with torch.device(_ROPE_DEVICE)`, rotary.py:133-141) every tensor op runs ON `device`,
+    so the table has the reference's bits on the CPU (golden fixtures) and on the GPU (reference-driven runs)."""
+    with torch.device(device):
+        return _cos_sin_cache(rotary_dim, max_position, base, rope_scaling)
+
+
+def _cos_sin_cache(rotary_dim: int, max_position: int, base: float,
+                   rope_scaling: Optional[Dict[str, Any]]) -> torch.Tensor:
     inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
     kind = None if rope_scaling is None else rope_scaling.get("rope_type", "default")
     if kind == "llama3":
@@ -71,7 +78,7 @@ def build_cos_sin_cache(rotary_dim: int, max_position: int, base: float,
         raise ValueError(f"Unsupported rope_scaling = {rope_scaling}")
     t = torch.arange(max_position, dtype=torch.float)
     freqs = torch.einsum("i,j -> ij", t, inv_freq)
-    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(device)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1)
 
 
 # ---- activation (P/layers/activation.py:9-18) ---------------------------------------------
@@ -82,10 +89,44 @@ def silu_and_mul(input: torch.Tensor, out: Optional[torch.Tensor] = None,
 
 def gelu_and_mul(input: torch.Tensor, out: Optional[torch.Tensor] = None,
                  enable_pdl: Optional[bool] = None) -> torch.Tensor:
-    raise NotImplementedError("gelu_and_mul: no dense model in scope uses it (SURVEY.md section 8)")
+    return ops.gelu_and_mul(input, out=out)
 
 
 # ---- sampling (P/engine/sample.py:30-45) --------------------------------------------------
+class _DeferredProbs:
+    """What `softmax(logits, T)` hands back: the reference's `sample_impl` (P/engine/sample.py:24-45) passes it
+    straight to one of the sampling functions and never looks inside.  Temperature-only batches are then drawn
+    by ONE fused kernel from the logits (no [B, V] fp32 probabilities tensor); the top-k / top-p functions
+    materialise the probabilities and run the radix-select kernel.  Anything else that treats the object as a
+    tensor gets the materialised tensor through `__torch_function__`-free explicit conversion (`.probs()`)."""
+
+    __slots__ = ("logits", "temperature", "_probs")
+
+    def __init__(self, logits: torch.Tensor, temperature: torch.Tensor) -> None:
+        self.logits, self.temperature, self._probs = logits, temperature, None
+
+    @property
+    def shape(self):
+        return self.logits.shape
+
+    @property
+    def device(self):
+        return self.logits.device
+
+    def fusable(self) -> bool:
+        lg = self.logits
+        return (lg.stride(0) * lg.element_size()) % 16 == 0 and lg.data_ptr() % 16 == 0
+
+    def probs(self) -> torch.Tensor:
+        if self._probs is None:
+            self._probs = ops.softmax_temperature(self.logits, self.temperature)
+        return self._probs
+
+
+def _as_probs(p) -> torch.Tensor:
+    return p.probs() if isinstance(p, _DeferredProbs) else p
+
+
 class _SamplingNamespace:
     """`import flashinfer.sampling as sampling` surface."""
 
@@ -99,12 +140,14 @@ class _SamplingNamespace:
 
     @staticmethod
     def softmax(logits: torch.Tensor, temperature: Optional[torch.Tensor] = None,
-                enable_pdl: Optional[bool] = None) -> torch.Tensor:
+                enable_pdl: Optional[bool] = None, *, deferred: bool = True):
         if temperature is None:
             temperature = torch.ones(logits.shape[0], dtype=torch.float32, device=logits.device)
-        return ops.softmax_temperature(logits, temperature)
+        d = _DeferredProbs(logits, temperature)
+        return d if deferred else d.probs()
 
     def _sample(self, probs, top_k, top_p):
+        probs = _as_probs(probs)
         dev = probs.device
         if isinstance(top_k, int):
             top_k = torch.full((probs.shape[0],), top_k, dtype=torch.int32, device=dev)
@@ -114,6 +157,8 @@ class _SamplingNamespace:
         return ops.sample_top_k_top_p(probs, top_k, top_p, torch.initial_seed(), self._next_offset(probs.shape[0]))
 
     def sampling_from_probs(self, probs, **_kw):
+        if isinstance(probs, _DeferredProbs) and probs.fusable():
+            return self.sampling_from_logits(probs.logits, probs.temperature)
         return self._sample(probs, None, None)
 
     def sampling_from_logits(self, logits, temperature, **_kw):

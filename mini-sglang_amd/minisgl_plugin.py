@@ -6,13 +6,27 @@ Seams filled:
   attention backend   SUPPORTED_ATTENTION_BACKENDS.register("hip")        P/attention/__init__.py:19-40
   minisgl.kernel      store_cache / indexing / fast_compare_key / init_pynccl   P/kernel/__init__.py
   flashinfer names    rmsnorm, fused_add_rmsnorm, apply_rope_with_cos_sin_cache_inplace,
-                      silu_and_mul, sampling.*                            P/layers/norm.py:10-30 ...
+                      silu_and_mul, gelu_and_mul, sampling.*              P/layers/norm.py:10-30 ...
+
+and, so that the path the reference drives is the path bench.py measures:
+  F.linear            the name `F` of P/layers/linear.py:32,103,124 and P/layers/embedding.py:98 resolves to a
+                      proxy of torch.nn.functional whose `linear` is ops.linear (bias / CPU / odd dtypes fall
+                      back to torch)
+  AttentionLayer      P/layers/attention.py:47-57 (split, q-norm, k-norm, RoPE, store_kv, attend: 5 launches)
+                      becomes one qk_norm_rope_store launch + attend, bit-identical to the unfused sequence
+  GEMM plans          before GraphRunner captures (P/engine/graph.py:105-147) every projection shape of every
+                      captured batch size is timed once (gemm_plan.tune_projection_gemms)
+All three are class / module attribute assignments made at install time; no reference file is edited.
 """
 from __future__ import annotations
 
 import importlib
+import os
 import sys
 import types
+from typing import Any, Dict, List, Optional
+
+_STATE: Dict[str, Any] = {"gemm_tune": "heuristic", "gemm_report": [], "fast_linear": False, "fused_attention": False}
 
 
 def _stub_zmq() -> None:
@@ -53,7 +67,151 @@ def _install_flashinfer_shim() -> None:
     sys.modules["flashinfer"], sys.modules["flashinfer.sampling"] = mod, samp
 
 
-def install(stub_zmq: bool = True) -> None:
+# ------------------------------------------------------------------------------ F.linear
+class _FunctionalProxy:
+    """Stands in for the module-level name `F` (= torch.nn.functional) of the reference's layer files: every
+    attribute is torch's except `linear`."""
+
+    def __init__(self) -> None:
+        import torch.nn.functional as F
+
+        self._F = F
+
+    def __getattr__(self, name: str) -> Any:
+        return getattr(self._F, name)
+
+    def linear(self, x, weight, bias=None):
+        import torch
+
+        from . import ops
+
+        if (bias is None and x.is_cuda and x.dtype == weight.dtype and x.dtype in (torch.bfloat16, torch.float16)
+                and weight.dim() == 2 and x.dim() >= 1 and x.shape[-1] == weight.shape[1] and weight.stride(1) == 1):
+            x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+            if x2.stride(1) == 1:
+                y = ops.linear(x2, weight)
+                return y if x.dim() == 2 else y.view(*x.shape[:-1], weight.shape[0])
+        return self._F.linear(x, weight, bias)
+
+
+def _install_fast_linear() -> None:
+    proxy = _FunctionalProxy()
+    for mod in ("minisgl.layers.linear", "minisgl.layers.embedding"):
+        importlib.import_module(mod).F = proxy
+    _STATE["fast_linear"] = True
+
+
+# ------------------------------------------------------------------------------ fused attention layer
+def _install_fused_attention() -> None:
+    from minisgl.core import get_global_ctx
+    from minisgl.layers.attention import AttentionLayer
+
+    from . import ops
+    from .attention import HipAttnBackend
+
+    if getattr(AttentionLayer.forward, "_msgl_fused", False):
+        return
+    reference_forward = AttentionLayer.forward
+
+    def forward(self, qkv):
+        ctx = get_global_ctx()
+        backend = ctx.attn_backend
+        if not isinstance(backend, HipAttnBackend) or not qkv.is_cuda:
+            return reference_forward(self, qkv)
+        batch = ctx.batch
+        D = self.head_dim
+        q, k, v = qkv.split([self.qo_attn_dim, self.kv_attn_dim, self.kv_attn_dim], dim=-1)
+        kv = ctx.kv_cache
+        kc, vc = kv.k_cache(self.layer_id), kv.v_cache(self.layer_id)
+        qn, kn = self.q_norm, self.k_norm
+        ops.qk_norm_rope_store(q, k, v, qn.weight if qn is not None else None, kn.weight if kn is not None else None,
+                               qn.eps if qn is not None else 0.0, batch.positions, self.rotary._cos_sin_cache,
+                               kc.view(-1, self.kv_attn_dim), vc.view(-1, self.kv_attn_dim), batch.out_loc, D)
+        o = backend.attend(q.view(-1, self.num_qo_heads, D), self.layer_id, batch)
+        return o.view(-1, self.qo_attn_dim)
+
+    forward._msgl_fused = True  # type: ignore[attr-defined]
+    forward._msgl_reference = reference_forward  # type: ignore[attr-defined]
+    AttentionLayer.forward = forward
+    _STATE["fused_attention"] = True
+
+
+# ------------------------------------------------------------------------------ GEMM plans before capture
+def _projection_groups(model: Any, require_device: bool = True) -> List[tuple]:
+    """(name, same-shaped weights of up to 8 layers, K) for every distinct linear shape in the reference's op tree
+    (P/layers/base.py:15-53: ops hold sub-ops as attributes, OPList in `op_list`) + the LM head."""
+    from minisgl.layers.base import BaseOP
+    from minisgl.layers.embedding import ParallelLMHead
+    from minisgl.layers.linear import _LinearTPImpl
+
+    found: Dict[tuple, List] = {}
+    names: Dict[tuple, str] = {}
+
+    def walk(op: Any, name: str) -> None:
+        if isinstance(op, _LinearTPImpl):
+            if op.bias is None and (op.weight.is_cuda or not require_device):
+                key = tuple(op.weight.shape)
+                found.setdefault(key, []).append(op.weight)
+                names.setdefault(key, name)
+            return
+        if isinstance(op, ParallelLMHead):
+            w = (op.tied_embedding or op).weight
+            if op.bias is None and (w.is_cuda or not require_device):
+                found.setdefault(tuple(w.shape), []).append(w)
+                names.setdefault(tuple(w.shape), "lm_head")
+            return
+        if isinstance(op, BaseOP):
+            for attr, sub in vars(op).items():
+                if isinstance(sub, BaseOP):
+                    walk(sub, attr)
+                elif isinstance(sub, (list, tuple)):
+                    for s in sub:
+                        if isinstance(s, BaseOP):
+                            walk(s, attr)
+
+    walk(model, "model")
+    groups = []
+    for shape, ws in found.items():
+        step = max(1, len(ws) // 8)
+        groups.append((names[shape].replace("_proj", ""), ws[::step][:8], shape[1]))
+    return groups
+
+
+def _install_tune_before_capture() -> None:
+    from minisgl.engine.graph import GraphRunner
+
+    if getattr(GraphRunner._capture_graphs, "_msgl_tuned", False):
+        return
+    reference_capture = GraphRunner._capture_graphs
+
+    def _capture_graphs(self, max_seq_len, vocab_size, model):
+        mode = _STATE["gemm_tune"]
+        if mode != "off" and self.max_graph_bs > 0 and _STATE["fast_linear"]:
+            import torch
+
+            from .gemm_plan import tune_projection_gemms
+
+            groups = _projection_groups(model)
+            if groups:
+                dtype = groups[0][1][0].dtype
+                log = (lambda m: print(m, file=sys.stderr)) if os.environ.get("MSGL_PLUGIN_VERBOSE") else None
+                _STATE["gemm_report"] = tune_projection_gemms(groups, list(self.graph_bs_list), mode, dtype,
+                                                              self.device, log=log)
+                torch.cuda.synchronize(self.device)
+        return reference_capture(self, max_seq_len, vocab_size, model)
+
+    _capture_graphs._msgl_tuned = True  # type: ignore[attr-defined]
+    GraphRunner._capture_graphs = _capture_graphs
+
+
+def gemm_report() -> List[dict]:
+    """What the last pre-capture search chose (one dict per (batch size, projection))."""
+    return list(_STATE["gemm_report"])
+
+
+def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True,
+            gemm_tune: Optional[str] = None) -> None:
+    """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic")."""
     if stub_zmq:
         _stub_zmq()
     _install_flashinfer_shim()
@@ -80,3 +238,10 @@ def install(stub_zmq: bool = True) -> None:
             from minisgl.distributed import get_tp_info
 
             return HipAttnBackend(config, ctx=get_global_ctx(), tp_size=get_tp_info().size)
+
+    _STATE["gemm_tune"] = gemm_tune or os.environ.get("MSGL_GEMM_TUNE", "heuristic")
+    if fast_linear:
+        _install_fast_linear()
+        _install_tune_before_capture()
+    if fused_attention:
+        _install_fused_attention()

@@ -156,50 +156,58 @@ class DenseDecoder:
             b -= self.embed.numel() * self.embed.element_size()
         return b
 
+    # ------------------------------------------------------------------ weights from a checkpoint
+    def load_hf_state(self, state: Dict[str, torch.Tensor]) -> None:
+        """Overwrite the seeded weights with HF-named tensors (full, unsharded), sharding and merging as
+        P/models/weight.py:34-124 does: q/k/v -> qkv, gate/up -> gate_up, column shards on dim 0, row shards
+        (o, down) on dim 1, vocab shards of embed_tokens / lm_head, KV heads replicated when tp > Hkv."""
+        cfg, r, n, D = self.cfg, self.tp_rank, self.tp_size, self.cfg.head_dim
+
+        def col(t):
+            return t.chunk(n, dim=0)[r]
+
+        def kv(t):
+            if cfg.num_kv_heads < n:
+                h = r * cfg.num_kv_heads // n
+                return t[h * D:(h + 1) * D]
+            return col(t)
+
+        def put(dst: torch.Tensor, src: torch.Tensor) -> None:
+            assert dst.shape == src.shape, (dst.shape, src.shape)
+            dst.copy_(src.to(device=self.device, dtype=self.dtype))
+
+        start, length = self.vocab_range
+        put(self.embed[:length], state["model.embed_tokens.weight"][start:start + length])
+        if not cfg.tie_word_embeddings:
+            put(self.lm_head[:length], state["lm_head.weight"][start:start + length])
+        put(self.final_norm, state["model.norm.weight"])
+        for i, lw in enumerate(self.layers):
+            p = f"model.layers.{i}."
+            put(lw.input_norm, state[p + "input_layernorm.weight"])
+            put(lw.post_norm, state[p + "post_attention_layernorm.weight"])
+            put(lw.qkv, torch.cat([col(state[p + "self_attn.q_proj.weight"]), kv(state[p + "self_attn.k_proj.weight"]),
+                                   kv(state[p + "self_attn.v_proj.weight"])], dim=0))
+            if lw.q_norm is not None:
+                put(lw.q_norm, state[p + "self_attn.q_norm.weight"])
+                put(lw.k_norm, state[p + "self_attn.k_norm.weight"])
+            put(lw.o, state[p + "self_attn.o_proj.weight"].chunk(n, dim=1)[r])
+            put(lw.gate_up, torch.cat([col(state[p + "mlp.gate_proj.weight"]), col(state[p + "mlp.up_proj.weight"])],
+                                      dim=0))
+            put(lw.down, state[p + "mlp.down_proj.weight"].chunk(n, dim=1)[r])
+
     # ------------------------------------------------------------------ GEMM solution search
-    def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None) -> List[dict]:
-        """Pick the fastest library solution for the five projection shapes at each decode batch size
-        (SURVEY.md section 8f rank 2).  mode: "off", "heuristic" (library's top 16), "full" (every
-        solution).  Weights of different layers are rotated so candidates are timed from HBM."""
-        if mode == "off" or not batch_sizes:
-            return []
-        # "full" pays only where a step is long: the largest batch; smaller graphs take the library's top 16
-        cands = {bs: ({"heuristic": -16, "full": 0}[mode] if bs == max(batch_sizes) else -16) for bs in batch_sizes}
-        report = []
+    def projection_groups(self):
+        """(name, same-shaped weights of up to 8 layers, K) of the five projection shapes."""
         step = max(1, len(self.layers) // 8)
         pick = self.layers[::step][:8]
-        groups = [("qkv", [l.qkv for l in pick], self.cfg.hidden_size),
-                  ("o", [l.o for l in pick], self.q_dim),
-                  ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size),
-                  ("down", [l.down for l in pick], self.inter),
-                  ("lm_head", [self.lm_head], self.cfg.hidden_size)]
-        for bs in batch_sizes:
-            for name, ws, k in groups:
-                x = torch.randn((bs, k), device=self.device, dtype=torch.float32).to(self.dtype)
-                r = ops.gemm_tune(x, ws, max_candidates=cands[bs], iters=8)
-                r["name"] = name
-                if bs <= ops.SKINNY_MAX_M:  # hand-written weight-streaming kernel vs the library's best
-                    sk = ops.skinny_tune(x, ws, r["best_us"])
-                    r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
-                             skinny_used=sk["used"])
-                    if sk["used"]:
-                        r["library_best_us"], r["best_us"] = r["best_us"], sk["skinny_us"]
-                        r["kernel"] = f"msgl::skinny_gemm_kernel[slices {sk['slices']}, row tiles {sk['row_tiles']}]"
-                if 32 < bs <= ops.WSTREAM_MAX_M and name != "lm_head":  # LDS-shared weight-streaming kernel
-                    wsr = ops.wstream_tune(x, ws, r["best_us"])
-                    r.update(wstream_us=wsr["wstream_us"], wstream_row_tiles=wsr["row_tiles"],
-                             wstream_k_splits=wsr["k_splits"], wstream_used=wsr["used"])
-                    if wsr["used"]:
-                        r.setdefault("library_best_us", r["best_us"])
-                        r["best_us"] = wsr["wstream_us"]
-                        r["skinny_used"] = True  # reported as hand-written by bench.py
-                        r["kernel"] = (f"msgl::wstream_gemm_kernel[row tiles {wsr['row_tiles']}, "
-                                       f"k splits {wsr['k_splits']}]")
-                report.append(r)
-                if log is not None:
-                    log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "
-                        f"({r['tried']} candidates) {r['kernel'][:100]}")
-        return report
+        return [("qkv", [l.qkv for l in pick], self.cfg.hidden_size), ("o", [l.o for l in pick], self.q_dim),
+                ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size),
+                ("down", [l.down for l in pick], self.inter), ("lm_head", [self.lm_head], self.cfg.hidden_size)]
+
+    def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None) -> List[dict]:
+        from .gemm_plan import tune_projection_gemms
+
+        return tune_projection_gemms(self.projection_groups(), batch_sizes, mode, self.dtype, self.device, log=log)
 
     # ------------------------------------------------------------------ forward
     def forward(self, ctx: Any, batch: Any) -> torch.Tensor:

@@ -179,7 +179,7 @@ def qk_norm_rope_store(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_norm
     )
 
 
-def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _act_and_mul(name: str, x: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
     _need_cuda(x)
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 2 == 0
     d = x.shape[1] // 2
@@ -187,11 +187,20 @@ def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
         out = torch.empty((x.shape[0], d), dtype=x.dtype, device=x.device)
     assert out.shape == (x.shape[0], d) and out.stride(1) == 1 and out.dtype == x.dtype
     check(
-        lib().msgl_silu_and_mul(out.data_ptr(), x.data_ptr(), x.shape[0], d, x.stride(0), out.stride(0), _dt(x),
-                                _stream()),
-        "silu_and_mul",
+        getattr(lib(), f"msgl_{name}")(out.data_ptr(), x.data_ptr(), x.shape[0], d, x.stride(0), out.stride(0),
+                                       _dt(x), _stream()),
+        name,
     )
     return out
+
+
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _act_and_mul("silu_and_mul", x, out)
+
+
+def gelu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Exact (erf) GELU gate, flashinfer.gelu_and_mul (P/layers/activation.py:15-18)."""
+    return _act_and_mul("gelu_and_mul", x, out)
 
 
 # ---------------------------------------------------------------------------- attention

@@ -1,0 +1,160 @@
+"""TEST INFRASTRUCTURE: one reference-driven scenario in a fresh process (see tests/refdrive.py).
+
+    python tests/refdrive_worker.py spec.json out.pt <dir holding the reference's `minisgl` package>
+
+Runs the REFERENCE's `LLM` (P/llm/llm.py:28-101: Scheduler + Engine + GraphRunner + CacheManager/radix cache,
+overlap loop) with `attention_backend="hip"` after `minisgl_plugin.install()`, and records, per forward the
+reference's engine executes, exactly what the hot path was handed (the `Batch`: phase, request rows, lengths,
+input ids, positions, out_loc, the page-table rows) and what it produced (logits summary, sampled ids), plus the
+generated token ids.  The recording wraps methods of the reference's *instances* from the outside; no reference
+source is modified.
+"""
+from __future__ import annotations
+
+import json
+import os
+import socket
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def logits_summary(logits):
+    """Bit-level fingerprint of a logits matrix: argmax, top-2 values, and an order-independent checksum of the
+    raw bit patterns per row (two matrices with equal checksums, argmax and top-2 are taken as bit-identical)."""
+    import torch
+
+    lf = logits.float()
+    top2 = lf.topk(2, dim=-1)
+    bits = lf.contiguous().view(torch.int32).to(torch.int64)
+    weights = torch.arange(1, lf.shape[1] + 1, device=lf.device, dtype=torch.int64)
+    return dict(argmax=top2.indices[:, 0].to(torch.int32).cpu(), top2=top2.values.cpu(),
+                checksum=(bits.sum(-1) + (bits * weights).sum(-1)).cpu(), dtype=str(logits.dtype))
+
+
+def main() -> None:
+    spec_path, out_path, ref_root = sys.argv[1:4]
+    spec = json.loads(Path(spec_path).read_text())
+    sys.path.insert(0, ref_root)
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import mini_sglang_amd.minisgl_plugin as plugin
+
+    plugin.install(fast_linear=spec.get("fast_linear", True), fused_attention=spec.get("fused_attention", True),
+                   gemm_tune=spec.get("gemm_tune", "off"))
+    import torch
+
+    from refdrive import write_model_dir
+
+    model_dir = spec.get("model_dir")
+    if model_dir is None:
+        model_dir = str(write_model_dir(Path(tempfile.mkdtemp(prefix="msgl_model_")) / spec["model"], spec["model"],
+                                        weights=spec.get("weights", "seeded") == "seeded",
+                                        max_position=spec.get("max_position", 40960)))
+
+    # the reference hard-wires tcp://127.0.0.1:2333 for its gloo group (P/engine/config.py:54-55); successive
+    # worker processes on one box would race for it
+    from minisgl.engine.config import EngineConfig
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    EngineConfig.distributed_addr = property(lambda self: f"tcp://127.0.0.1:{port}")  # type: ignore[assignment]
+
+    from minisgl.core import SamplingParams
+    from minisgl.llm import LLM
+
+    kw = dict(spec.get("llm_kwargs", {}))
+    kw.setdefault("attention_backend", "hip")
+    kw["use_dummy_weight"] = spec.get("weights", "seeded") == "dummy"
+    t0 = time.perf_counter()
+    llm = LLM(model_dir, **kw)
+    init_s = time.perf_counter() - t0
+    engine = llm.engine
+
+    record_level = spec.get("record", "batches")  # "none" | "timing" | "batches"
+    full_logits = int(spec.get("full_logits_forwards", 0))
+    forwards = []
+    state = dict(round=0)
+    orig_forward_batch, orig_sample = engine.forward_batch, engine.sampler.sample
+
+    def forward_batch(batch, args):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        e = dict(round=state["round"], phase=batch.phase, size=batch.size, padded_size=batch.padded_size, event=ev,
+                 total_tokens=int(sum(r.extend_len for r in batch.padded_reqs)))
+        if record_level == "batches":
+            padded = batch.padded_reqs
+            rows = [r.table_idx for r in padded]
+            max_len = max(r.device_len for r in padded)
+            e.update(uids=[r.uid for r in padded], rows=rows, cached_lens=[r.cached_len for r in padded],
+                     device_lens=[r.device_len for r in padded], chunked=[type(r).__name__ == "ChunkedReq" for r in padded],
+                     input_ids=batch.input_ids.clone(), positions=batch.positions.clone(), out_loc=batch.out_loc.clone(),
+                     table=engine.page_table[torch.tensor(rows, device=engine.device)][:, :max_len].clone(),
+                     metadata_type=type(batch.attn_metadata).__name__,
+                     graph=bool(engine.graph_runner.can_use_cuda_graph(batch)))
+        forwards.append(e)
+        out = orig_forward_batch(batch, args)
+        if record_level == "batches":
+            e["next_tokens"] = out.next_tokens_gpu.clone()
+        return out
+
+    def sample(logits, args):
+        e = forwards[-1]
+        if record_level == "batches":
+            e["summary"] = logits_summary(logits)
+            if len([f for f in forwards if "logits" in f]) < full_logits:
+                e["logits"] = logits.float().cpu()
+        return orig_sample(logits, args)
+
+    if record_level != "none":
+        engine.forward_batch = forward_batch
+        engine.sampler.sample = sample
+
+    outputs, walls = [], []
+    for ri, rnd in enumerate(spec["rounds"]):
+        state["round"] = ri
+        sps = [SamplingParams(**sp) for sp in rnd["sampling"]]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = llm.generate(rnd["prompts"], sps)
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+        outputs.append([r["token_ids"] for r in res])
+
+    # timing: ms between the starts of consecutive forwards (steady-state step time incl. host work)
+    for a, b in zip(forwards[:-1], forwards[1:]):
+        a["ms_to_next"] = a["event"].elapsed_time(b["event"]) if a["round"] == b["round"] else None
+    for f in forwards:
+        f.pop("event", None)
+        for k, v in list(f.items()):
+            if isinstance(v, torch.Tensor):
+                f[k] = v.cpu()
+
+    cm = llm.cache_manager
+    rec = dict(spec=spec, outputs=outputs, walls=walls, forwards=forwards, init_s=init_s,
+               num_pages=engine.num_pages, max_seq_len=engine.max_seq_len, page_table_shape=tuple(engine.page_table.shape),
+               graph_bs=list(engine.graph_runner.graph_bs_list), backend=type(engine.attn_backend).__name__,
+               attention_forward_fused=bool(getattr(type(engine.model.model.layers.op_list[0].self_attn.attn).forward,
+                                                    "_msgl_fused", False)),
+               gemm_report=plugin.gemm_report(), free_pages_end=int(len(cm.free_slots)),
+               evictable_end=int(cm.prefix_cache.size_info.evictable_size), device=torch.cuda.get_device_name(0))
+    try:
+        cm.check_integrity()
+        rec["integrity"] = "ok"
+    except Exception as e:  # recorded, asserted by the test
+        rec["integrity"] = f"{type(e).__name__}: {e}"
+    torch.save(rec, out_path)
+    try:
+        llm.shutdown()
+    except Exception as e:
+        print(f"[worker] shutdown: {type(e).__name__}: {e}", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

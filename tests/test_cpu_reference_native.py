@@ -1,0 +1,97 @@
+"""CPU checks against the reference's own code:
+
+* `oracle/_ref/libref_radix.so` is /root/reference/python/minisgl/kernel/csrc/src/radix.cpp compiled unmodified
+  (oracle/build_ref.sh); the product's `msgl_fast_compare_key` and the plain-C oracle must agree with it on
+  every input, and fail where it fails.
+* `minisgl_plugin.install()` against the reference's Python package: every seam the INTEGRATION table lists is
+  actually rebound (F.linear proxy, fused AttentionLayer.forward, pre-capture GEMM search, kernels, registry).
+"""
+import os
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import pytest
+import torch
+
+import refdrive
+from oracle import bytes_c, ref_native
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.skipif(not ref_native.available(), reason="oracle/_ref/libref_radix.so not built")
+def test_fast_compare_key_matches_the_compiled_reference():
+    from mini_sglang_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    cases = []
+    for dt in (torch.int32, torch.int64):
+        for n, m in [(0, 0), (0, 5), (1, 1), (7, 7), (64, 33), (1000, 1000), (4097, 40000)]:
+            x = torch.randint(0, 50000, (n,), generator=g).to(dt)
+            y = torch.randint(0, 50000, (m,), generator=g).to(dt)
+            k = min(n, m)
+            for cut in {0, min(1, k), k // 2, max(k - 1, 0), k}:
+                y2 = y.clone()
+                y2[:cut] = x[:cut]
+                cases.append((x, y2))
+            cases.append((x, x.clone()))
+    assert len(cases) > 60
+    for x, y in cases:
+        want = ref_native.fast_compare_key(x, y)
+        assert ops.fast_compare_key(x, y) == want
+        assert bytes_c.compare_key(x, y) == want
+    # error behaviour (C/src/radix.cpp:22-23): mixed dtypes, non-contiguous, wrong rank
+    a, b = torch.arange(8, dtype=torch.int32), torch.arange(8, dtype=torch.int64)
+    for bad in [(a, b), (a[::2], a), (a.view(2, 4), a)]:
+        with pytest.raises(RuntimeError):
+            ref_native.fast_compare_key(*bad)
+        with pytest.raises(RuntimeError):
+            ops.fast_compare_key(*bad)
+
+
+@pytest.mark.skipif(refdrive.reference_root() is None, reason="no importable reference")
+def test_install_rebinds_every_seam_of_the_reference():
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {str(refdrive.reference_root())!r}); sys.path.insert(0, {str(ROOT)!r})
+        import torch
+        import mini_sglang_amd.minisgl_plugin as plugin
+        plugin.install(gemm_tune="off")
+        import minisgl.kernel as mk, minisgl.layers.linear as ll, minisgl.layers.embedding as le
+        from minisgl.layers.attention import AttentionLayer
+        from minisgl.engine.graph import GraphRunner
+        from minisgl.attention import SUPPORTED_ATTENTION_BACKENDS, validate_attn_backend
+        from mini_sglang_amd import kernel as k
+        assert mk.store_cache is k.store_cache and mk.indexing is k.indexing and mk.init_pynccl is k.init_pynccl
+        assert validate_attn_backend("hip") == "hip" and validate_attn_backend("hip,hip")
+        assert type(ll.F).__name__ == "_FunctionalProxy" and le.F is ll.F
+        x, w, b = torch.randn(3, 8), torch.randn(5, 8), torch.randn(5)
+        assert torch.equal(ll.F.linear(x, w, b), torch.nn.functional.linear(x, w, b))   # CPU / bias: torch
+        assert ll.F.silu is torch.nn.functional.silu                                     # everything else: torch
+        assert AttentionLayer.forward._msgl_fused and GraphRunner._capture_graphs._msgl_tuned
+        import flashinfer, flashinfer.sampling
+        for n in ("rmsnorm", "fused_add_rmsnorm", "apply_rope_with_cos_sin_cache_inplace", "silu_and_mul", "gelu_and_mul"):
+            assert callable(getattr(flashinfer, n))
+        # the op tree walk finds the five projection shapes of a dense model
+        from minisgl.distributed import set_tp_info
+        from minisgl.layers import set_rope_device
+        from minisgl.models import ModelConfig, create_model
+        from minisgl.utils import cached_load_hf_config
+        import refdrive, tempfile, pathlib
+        d = refdrive.write_model_dir(pathlib.Path(tempfile.mkdtemp()) / "tiny", "tiny", weights=False, max_position=512)
+        set_tp_info(rank=0, size=1); set_rope_device(torch.device("cpu"))
+        model = create_model(ModelConfig.from_hf(cached_load_hf_config(str(d))))
+        groups = plugin._projection_groups(model, require_device=False)
+        got = sorted((n, tuple(ws[0].shape), len(ws), kk) for n, ws, kk in groups)
+        # plans are keyed by shape: at the tiny dims the LM head (1024, 256) shares gate_up's shape and group
+        want = sorted([("qkv", (1792, 256), 2, 256), ("o", (256, 1280), 2, 1280), ("gate_up", (1024, 256), 3, 256),
+                       ("down", (256, 512), 2, 512)])
+        assert got == want, got
+        plugin.install(gemm_tune="off")   # idempotent
+        print("seams ok")
+    """)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(ROOT / "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "seams ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

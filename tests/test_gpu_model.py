@@ -99,6 +99,23 @@ def test_chunked_prefill_matches_unchunked(dev):
     assert ids1 == ids2
 
 
+def test_prefill_batch_of_one_token_extensions_runs_eagerly_with_graphs_captured(dev):
+    """Round-1 crash (ADVICE high, attention.py:149): a PREFILL-phase batch whose every request extends by one
+    token (chunk remainder of 1 here; a radix full hit in the reference) at a captured batch size took the decode
+    kernel with no plan.  prompt_len = budget + 1 => the second chunk is exactly that batch."""
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.randint(0, 1000, (65,), generator=g).tolist()]
+    e1 = make_engine(dev, graphs=True)
+    rec = []
+    ids1, _, _ = run(e1, ps, 5, record=rec, max_extend=64)
+    e1.shutdown()
+    assert [r["phase"] for r in rec[:2]] == ["prefill", "prefill"] and rec[1]["q_lens"] == [1] and rec[1]["k_lens"] == [65]
+    e2 = make_engine(dev, graphs=True)
+    ids2, _, _ = run(e2, ps, 5)  # unchunked
+    e2.shutdown()
+    assert ids1 == ids2
+
+
 @pytest.mark.parametrize("name,page_size", [("tiny", 4), ("tiny-llama", 1)])
 def test_teacher_forced_parity_vs_cpu_oracle(dev, name, page_size):
     ps = prompts(5)

@@ -1,0 +1,317 @@
+"""The reference's OWN host code drives the MI355X hot path.
+
+Each scenario runs `minisgl.llm.LLM` (P/llm/llm.py:28-101) -- its Scheduler / overlap loop
+(P/scheduler/scheduler.py:83-233), PrefillManager (chunked prefill, P/scheduler/prefill.py:65-151), CacheManager +
+RadixPrefixCache (P/scheduler/cache.py:27-146), Engine and GraphRunner (P/engine/graph.py:105-166) -- with
+`attention_backend="hip"` after `minisgl_plugin.install()`, in a fresh process (tests/refdrive_worker.py), and
+records every Batch the reference handed to the hot path.  Checks:
+
+  1. REPLAY: the recorded batches (same rows, lengths, ids, positions, out_loc, page-table rows) are fed in order
+     to this repository's engine (mini-sglang_amd/engine.py) holding the same weights; logits must be BIT-IDENTICAL
+     (argmax, top-2 and a checksum of the raw bits, per row): the drop-in path and the benchmarked path are the
+     same kernels.  KV block indices are identical by construction here -- they are the reference's own.
+  2. IDS: where batch composition is trivially the same (one request), the reference-driven token ids equal the
+     repo driver's (OfflineRunner) ids.
+  3. ORACLE: tiny dims, teacher-forced through oracle/ref_model.py on the recorded inputs: logits within the
+     stated tolerance with the error distribution printed, greedy ids equal wherever the oracle margin is sure.
+  4. The radix full-hit case (prefill batch, every extend_len == 1, bs in the captured sizes) that crashed in
+     round 1 (`attention.py` plan=None) is reached and passes.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+from pathlib import Path
+
+import pytest
+import torch
+
+import parity_stats
+import refdrive
+from refdrive_worker import logits_summary
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(refdrive.reference_root() is None, reason="no importable reference (oracle/_ref)")]
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_TOL = 3e-2  # tiny dims (2 layers, logit std ~0.3): measured max 1.6e-2 in round 1; distribution printed
+
+
+# ------------------------------------------------------------------------------ fixtures
+@pytest.fixture(scope="module")
+def model_dirs(tmp_path_factory):
+    """Seeded checkpoints written once per module; the same tensors are loaded into the repo engine."""
+    base = tmp_path_factory.mktemp("msgl_models")
+    cache = {}
+
+    def get(model: str):
+        if model not in cache:
+            d = refdrive.write_model_dir(base / model, model, weights=True, max_position=4096 if model == "tiny" else 40960)
+            from safetensors.torch import load_file
+
+            cache[model] = (str(d), load_file(str(d / "model.safetensors")))
+        return cache[model]
+
+    return get
+
+
+def repo_engine(dev, model: str, state, rec, llm_kwargs):
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.model import PRESETS
+
+    cfg = EngineConfig(model=PRESETS[model], dtype=torch.bfloat16, max_running_req=llm_kwargs["max_running_req"],
+                       page_size=llm_kwargs["page_size"], cuda_graph_bs=list(rec["graph_bs"]),
+                       max_seq_len_override=llm_kwargs["max_seq_len_override"], num_page_override=rec["num_pages"],
+                       fused_qkv_path=True, gemm_tune="off")
+    eng = Engine(cfg, dev)
+    eng.model.load_hf_state(state)
+    assert tuple(eng.page_table.shape) == tuple(rec["page_table_shape"])
+    return eng
+
+
+def replay(eng, rec):
+    """Feed the reference's recorded batches to the repo engine; returns per-forward summaries."""
+    from mini_sglang_amd.core import Batch, Req
+
+    dev = eng.device
+    out = []
+    for f in rec["forwards"]:
+        rows = torch.tensor(f["rows"], device=dev)
+        table = f["table"].to(dev)
+        eng.page_table[rows, : table.shape[1]] = table
+        reqs = [Req(input_ids=torch.zeros(dl, dtype=torch.int32), table_idx=row, cached_len=cl, output_len=1 << 20,
+                    uid=uid) for row, cl, dl, uid in zip(f["rows"], f["cached_lens"], f["device_lens"], f["uids"])]
+        batch = Batch(reqs=reqs[: f["size"]], phase=f["phase"])
+        batch.padded_reqs = reqs
+        batch.input_ids, batch.positions, batch.out_loc = (f[k].to(dev) for k in ("input_ids", "positions", "out_loc"))
+        eng.attn_backend.prepare_metadata(batch)
+        with eng.ctx.forward_batch(batch):
+            use_graph = eng.graph_runner.can_use_cuda_graph(batch)
+            assert use_graph == f["graph"], "the two engines disagree on graph replay for this batch"
+            logits = eng.graph_runner.replay(batch) if use_graph else eng.model.forward(eng.ctx, batch)
+        out.append(logits_summary(logits[: f["size"]]))
+    return out
+
+
+def assert_bit_identical(rec, mine):
+    bad = []
+    for i, (f, s) in enumerate(zip(rec["forwards"], mine)):
+        r = f["summary"]
+        ok = (r["dtype"] == s["dtype"] and torch.equal(r["argmax"], s["argmax"]) and torch.equal(r["top2"], s["top2"])
+              and torch.equal(r["checksum"], s["checksum"]))
+        if not ok:
+            d = (r["top2"] - s["top2"]).abs().max().item() if r["top2"].shape == s["top2"].shape else float("nan")
+            bad.append((i, f["phase"], f["size"], f["padded_size"], f["graph"], d))
+    assert not bad, f"{len(bad)} of {len(mine)} forwards differ between reference-driven and repo engine: {bad[:8]}"
+
+
+def greedy(n_tokens):
+    return dict(temperature=0.0, max_tokens=n_tokens, ignore_eos=True)
+
+
+def dump(name, obj):
+    """Keep a copy of what a scenario measured where gpurun merges files back."""
+    out = ROOT / "gpurun_out"
+    if out.is_dir():
+        (out / name).write_text(json.dumps(obj, indent=1, default=str))
+
+
+# ------------------------------------------------------------------------------ (a) BASELINE config 0
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_reference_driven_config0_qwen3_0p6b(dev, model_dirs, page_size):
+    """BASELINE.json configs[0] on the GPU through the reference's LLM: one 32-token prompt, 32 greedy tokens."""
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.offline import OfflineRunner
+
+    mdir, state = model_dirs("qwen3-0.6b")
+    rnd = random.Random(0)
+    prompt = [rnd.randint(0, 10000) for _ in range(32)]
+    kw = dict(page_size=page_size, max_running_req=8, cuda_graph_bs=[1, 2, 4], max_seq_len_override=256,
+              num_page_override=4096 // page_size, max_extend_tokens=8192, cache_type="radix")
+    rec = refdrive.run_worker(dict(model="qwen3-0.6b", model_dir=mdir, llm_kwargs=kw,
+                                   rounds=[dict(prompts=[prompt], sampling=[greedy(32)])]))
+    assert rec["backend"] == "HipAttnBackend" and rec["attention_forward_fused"] and rec["integrity"] == "ok"
+    ids = rec["outputs"][0][0]
+    assert len(ids) == 32
+    phases = [f["phase"] for f in rec["forwards"]]
+    assert phases == ["prefill"] + ["decode"] * 31 and all(f["graph"] for f in rec["forwards"][1:])
+    # KV block indices: out_loc is the page table's slot for the position, every step
+    for f in rec["forwards"]:
+        n_real = f["device_lens"][0] - f["cached_lens"][0]
+        assert torch.equal(f["out_loc"][:n_real].long(), f["table"][0][f["positions"][:n_real].long()].long())
+    eng = repo_engine(dev, "qwen3-0.6b", state, rec, kw)
+    assert_bit_identical(rec, replay(eng, rec))
+    eng.shutdown()
+    # the repo's own driver on the same request: same ids (same batch composition at every step)
+    eng = repo_engine(dev, "qwen3-0.6b", state, rec, kw)
+    runner = OfflineRunner(eng, max_extend_tokens=8192, seed=0)
+    runner.generate([prompt], [SamplingParams(temperature=0.0, max_tokens=32, ignore_eos=True)])
+    mine = runner.output_ids(runner.last_states[0])
+    eng.shutdown()
+    assert mine == ids, "greedy ids of the reference-driven run and the repo driver differ"
+
+
+# ------------------------------------------------------------------------------ (b)+(c) radix / chunked / repeats, tiny dims
+def tiny_rounds():
+    g = random.Random(7)
+
+    def ids(n):
+        return [g.randint(0, 999) for _ in range(n)]
+
+    a = ids(70)
+    b = a[:40] + ids(30)           # shares a 40-token prefix with a
+    c = ids(33)
+    d = ids(130)                   # chunked at max_extend_tokens = 64
+    e = ids(1)                     # one-token prompt
+    round0 = [a, b, c, d, e, list(a)]
+    round1 = [list(a)]             # exact repeat, alone: radix full hit -> a prefill batch with extend_len == 1
+    round2 = [a[:55] + ids(20), list(d), b[:64] + ids(5), list(c)]
+    return [round0, round1, round2]
+
+
+def cpu_weights_from_hf(state, cfg):
+    from oracle import ref_model, ref_ops
+
+    layers = []
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        layers.append(dict(
+            input_norm=state[p + "input_layernorm.weight"],
+            qkv=torch.cat([state[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], dim=0),
+            q_norm=state[p + "self_attn.q_norm.weight"], k_norm=state[p + "self_attn.k_norm.weight"],
+            o=state[p + "self_attn.o_proj.weight"], post_norm=state[p + "post_attention_layernorm.weight"],
+            gate_up=torch.cat([state[p + "mlp.gate_proj.weight"], state[p + "mlp.up_proj.weight"]], dim=0),
+            down=state[p + "mlp.down_proj.weight"]))
+    lm = state["model.embed_tokens.weight"] if cfg.tie_word_embeddings else state["lm_head.weight"]
+    cos_sin = ref_ops.rope_cos_sin_cache(cfg.head_dim, cfg.max_position, cfg.rope_base, cfg.rope_scaling)
+    return ref_model.CpuWeights(state["model.embed_tokens.weight"], layers, state["model.norm.weight"], lm, cos_sin)
+
+
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_reference_driven_radix_chunked_prefill_and_repeats_tiny(dev, model_dirs, page_size):
+    from mini_sglang_amd.model import PRESETS
+    from oracle import ref_model
+
+    mdir, state = model_dirs("tiny")
+    kw = dict(page_size=page_size, max_running_req=8, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512,
+              num_page_override=4096 // page_size, max_extend_tokens=64, cache_type="radix")
+    rounds = [dict(prompts=ps, sampling=[greedy(6)] * len(ps)) for ps in tiny_rounds()]
+    rec = refdrive.run_worker(dict(model="tiny", model_dir=mdir, llm_kwargs=kw, rounds=rounds,
+                                   full_logits_forwards=10 ** 9, max_position=4096))
+    assert rec["backend"] == "HipAttnBackend" and rec["integrity"] == "ok"
+    fw = rec["forwards"]
+    assert all(len(o) == 6 for r in rec["outputs"] for o in r)
+    # the scheduler really did what the scenario is about
+    assert any(any(f["chunked"]) for f in fw), "no chunked prefill happened"
+    hits = [f for f in fw if f["phase"] == "prefill" and any(c > 0 and not ch for c, ch in zip(f["cached_lens"], f["chunked"]))]
+    assert hits, "no radix-cache hit happened"
+    if page_size == 1:
+        full = [f for f in fw if f["round"] == 1 and f["phase"] == "prefill"]
+        assert len(full) == 1 and full[0]["size"] == 1 and full[0]["cached_lens"][0] == 69 and full[0]["device_lens"][0] == 70
+        assert not full[0]["graph"], "a prefill-phase batch must not be graph-replayed"
+        # the repeated prompt continues exactly as the first time (greedy, same context)
+        assert rec["outputs"][1][0] == rec["outputs"][0][0]
+
+    # 1. replay through the repo engine: bit-identical logits
+    eng = repo_engine(dev, "tiny", state, rec, kw)
+    assert_bit_identical(rec, replay(eng, rec))
+    eng.shutdown()
+
+    # 3. teacher-forced oracle
+    cfg = PRESETS["tiny"]
+    w = cpu_weights_from_hf(state, cfg)
+    slots = (rec["num_pages"] + 1) * page_size
+    kp = [torch.zeros((slots, cfg.num_kv_heads, cfg.head_dim), dtype=torch.bfloat16) for _ in range(cfg.num_layers)]
+    vp = [torch.zeros_like(k) for k in kp]
+    stats, agree, total = {}, 0, 0
+    for f in fw:
+        n = f["padded_size"]
+        q_lens = [d - c for c, d in zip(f["cached_lens"], f["device_lens"])]
+        ref = ref_model.forward(cfg, w, f["input_ids"], f["positions"], f["out_loc"], kp, vp, f["table"], list(range(n)),
+                                f["device_lens"], q_lens, f["phase"] == "prefill").float()[: f["size"]]
+        got = f["logits"]
+        stats = parity_stats.merge_stats(stats, parity_stats.logit_error_stats(got, ref))
+        assert (got - ref).abs().max().item() <= ORACLE_TOL, parity_stats.fmt(parity_stats.logit_error_stats(got, ref))
+        top2 = ref.topk(2, dim=-1).values
+        sure = (top2[:, 0] - top2[:, 1]) > 2 * ORACLE_TOL
+        same = got.argmax(-1) == ref.argmax(-1)
+        assert bool(same[sure].all())
+        agree, total = agree + int(same.sum()), total + same.numel()
+    print(f"\n[refdrive tiny ps={page_size}] {len(fw)} forwards, oracle parity: {parity_stats.fmt(stats)}; "
+          f"argmax agreement {agree}/{total}")
+    dump(f"refdrive_tiny_ps{page_size}.json", dict(stats=stats, forwards=len(fw), argmax_agree=agree, rows=total,
+                                                   hits=len(hits), outputs=rec["outputs"]))
+    assert agree >= 0.9 * total
+
+
+# ------------------------------------------------------------------------------ (b) 16-request slice of the offline bench, 0.6B
+@pytest.mark.parametrize("page_size", [1, 256])
+def test_reference_driven_offline_bench_slice_qwen3_0p6b(dev, model_dirs, page_size):
+    mdir, state = model_dirs("qwen3-0.6b")
+    prompts, outs = refdrive.offline_bench_requests(16, max_out=12)
+    # shared-prefix variant: the last four requests start with request 0's first 256 ids,
+    # and one is an exact repeat of request 1
+    prompts = [list(p) for p in prompts]
+    for i in (12, 13, 14):
+        prompts[i] = prompts[0][:256] + prompts[i][256:]
+    prompts[15] = list(prompts[1])
+    kw = dict(page_size=page_size, max_running_req=16, cuda_graph_bs=[1, 2, 4, 8, 16], max_seq_len_override=2048,
+              num_page_override=32768 // page_size, max_extend_tokens=2048, cache_type="radix")
+    rec = refdrive.run_worker(dict(model="qwen3-0.6b", model_dir=mdir, llm_kwargs=kw,
+                                   rounds=[dict(prompts=prompts, sampling=[greedy(o) for o in outs])]))
+    assert rec["integrity"] == "ok" and [len(o) for o in rec["outputs"][0]] == outs
+    fw = rec["forwards"]
+    n_prefill = sum(f["phase"] == "prefill" for f in fw)
+    assert n_prefill >= 4 and any(any(f["chunked"]) for f in fw), "prefill was not chunked"
+    hit_tokens = sum(c for f in fw if f["phase"] == "prefill" for c, ch in zip(f["cached_lens"], f["chunked"]) if not ch)
+    assert hit_tokens >= 256, "the shared prefix / repeated prompt did not hit the radix cache"
+    eng = repo_engine(dev, "qwen3-0.6b", state, rec, kw)
+    assert_bit_identical(rec, replay(eng, rec))
+    eng.shutdown()
+    dump(f"refdrive_slice_0p6b_ps{page_size}.json",
+         dict(forwards=len(fw), prefill_forwards=n_prefill, radix_hit_tokens=hit_tokens, wall_s=rec["walls"],
+              decode_ms=[f.get("ms_to_next") for f in fw if f["phase"] == "decode"][:8]))
+
+
+# ------------------------------------------------------------------------------ the headline workload through the reference
+@pytest.mark.skipif(os.environ.get("MSGL_SKIP_14B_REFDRIVE") == "1", reason="disabled by MSGL_SKIP_14B_REFDRIVE")
+def test_reference_driven_qwen3_14b_decode_step_is_the_benchmarked_path(dev):
+    """bench.py's workload (Qwen3-14B bf16, 256 sequences, offline-bench context distribution, page_size 256,
+    temperature 0.6, chunked prefill 16384, hipGraph at bs 256, GEMM plans searched before capture) executed by
+    the REFERENCE's LLM / Scheduler / GraphRunner through install(): the decode step must cost what bench.py
+    measures with the repo's own driver (within a few percent).  Random (`use_dummy_weight`)
+    weights: only time is compared here; parity is pinned by the scenarios above."""
+    free, total = torch.cuda.mem_get_info()
+    if total < 200 * (1 << 30):
+        pytest.skip("needs a 288 GB part")
+    from bench import bench_contexts
+
+    B, steps = 256, 45
+    contexts = bench_contexts(B)
+    rnd = random.Random(1234)
+    prompts = [[rnd.randint(0, 10000) for _ in range(n)] for n in contexts]
+    sp = dict(temperature=0.6, max_tokens=steps, ignore_eos=True)
+    kw = dict(page_size=256, max_running_req=B, cuda_graph_bs=[B], max_seq_len_override=4096,
+              max_extend_tokens=16384, cache_type="radix", memory_ratio=0.9)
+    rec = refdrive.run_worker(
+        dict(model="qwen3-14b", weights="dummy", llm_kwargs=kw, record="timing", gemm_tune="full",
+             rounds=[dict(prompts=[[1, 2, 3, 4]], sampling=[dict(temperature=0.1, max_tokens=4, ignore_eos=True)]),
+                     dict(prompts=prompts, sampling=[sp] * B)]), timeout=1500)
+    fw = [f for f in rec["forwards"] if f["round"] == 1]
+    dec = [f for f in fw if f["phase"] == "decode" and f["size"] == B and f.get("ms_to_next")]
+    assert len(dec) >= 30, f"only {len(dec)} full-batch decode steps were observed"
+    ms = sorted(f["ms_to_next"] for f in dec[3:])
+    med = ms[len(ms) // 2]
+    pre = [f for f in fw if f["phase"] == "prefill"]
+    report = dict(decode_ms_per_step_median=med, decode_ms_min=ms[0], decode_ms_max=ms[-1], steps=len(ms),
+                  tokens_per_s=B * 1e3 / med, prefill_forwards=len(pre), prefill_tokens=sum(f["total_tokens"] for f in pre),
+                  wall_s=rec["walls"][1], e2e_tokens_per_s=B * steps / rec["walls"][1], init_s=rec["init_s"],
+                  gemm=[dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], us=round(r["best_us"], 1),
+                             kernel=r["kernel"][:80]) for r in rec["gemm_report"]],
+                  driver="reference LLM/Scheduler/GraphRunner via minisgl_plugin.install()", device=rec["device"])
+    print(f"\n[refdrive 14B] decode {med:.2f} ms/step ({B * 1e3 / med:.0f} tok/s) over {len(ms)} steps "
+          f"[{ms[0]:.2f}..{ms[-1]:.2f}], prefill {len(pre)} chunks")
+    dump("refdrive_14b.json", report)
+    assert rec["attention_forward_fused"] and rec["gemm_report"], "fast path was not wired into the reference"
+    assert med < 25.0, f"reference-driven decode step {med:.2f} ms is far off the benchmarked path"
