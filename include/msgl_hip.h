@@ -244,6 +244,17 @@ int msgl_wstream_gemm_nt(void* out, const void* x, const void* w, int M, int N, 
                          int64_t ldw, int64_t ldo, int dtype, int row_tiles, int k_splits,
                          void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Full-batch decode projection, 128 < M <= 256 (csrc/gemm_m256.hip): the same `F.linear` of
+ * P/layers/linear.py:32,103,124.  One workgroup per CU walks 256 x 128 output tiles with both operands staged
+ * by LDS-DMA through a three-stage ring and v_mfma_f32_32x32x16.  Plan = (grid, full, tail_split): the first
+ * `full` tiles of N / 128 are computed whole, the rest are cut into `tail_split` k-slices spread over all
+ * workgroups (fp32 slabs in `workspace`, added in slice order by a second kernel: deterministic).
+ * N % 128 == 0, K % 64 == 0. */
+int64_t msgl_m256_gemm_workspace_bytes(int M, int N, int full, int tail_split);
+int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                      int64_t ldo, int dtype, int grid, int full, int tail_split, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Tensor-parallel communicator over RCCL (libmsgl_comm.so).  Replaces
  * NCCLWrapper (C/src/pynccl.cu:72-175) / init_pynccl (P/kernel/pynccl.py:47-78).

@@ -63,6 +63,8 @@ HIP_SIGNATURES = {
     "msgl_skinny_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
     "msgl_wstream_gemm_workspace_bytes": (_l, [_i, _i, _i]),
     "msgl_wstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _l, _p]),
+    "msgl_m256_gemm_workspace_bytes": (_l, [_i, _i, _i, _i]),
+    "msgl_m256_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
 }
 
 COMM_SIGNATURES = {

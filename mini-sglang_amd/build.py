@@ -36,6 +36,7 @@ HIP_SOURCES = [
     "sampling.hip",
     "gemm_skinny.hip",
     "gemm_wstream.hip",
+    "gemm_m256.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]
 GEMM_SOURCES = ["gemm.cpp"]
@@ -47,6 +48,7 @@ COMMON_FLAGS = [
     f"--offload-arch={ARCH}",
     "-Wall",
     "-Wno-unused-function",
+    "-Wno-inline-asm",
     "-I",
     str(INCLUDE),
 ]

@@ -51,6 +51,14 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r["skinny_used"] = True  # reported as hand-written by bench.py
                     r["kernel"] = (f"msgl::wstream_gemm_kernel[row tiles {wsr['row_tiles']}, "
                                    f"k splits {wsr['k_splits']}]")
+            if ops.m256_supported(bs, r["N"], r["K"]):  # one workgroup per CU, LDS-DMA ring (gemm_m256.hip)
+                mr = ops.m256_tune(x, ws, r["best_us"])
+                r.update(m256_us=mr["m256_us"], m256_plan=mr["plan"], m256_used=mr["used"], m256_all=mr.get("all"))
+                if mr["used"]:
+                    r.setdefault("library_best_us", r["best_us"])
+                    r["best_us"] = mr["m256_us"]
+                    r["skinny_used"] = True
+                    r["kernel"] = "msgl::m256_gemm_kernel[grid %d, whole tiles %d, k-slices %d]" % tuple(mr["plan"])
             report.append(r)
             if log is not None:
                 log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "

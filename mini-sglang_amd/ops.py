@@ -523,6 +523,95 @@ def wstream_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) 
     return res
 
 
+# ---- full decode batches: one workgroup per CU, LDS-DMA ring, 32x32x16 MFMA (csrc/gemm_m256.hip)
+_M256_PLAN: dict = {}  # (device, M, N, K, ldx, ldw, dtype code) -> (grid, full, tail_split)
+M256_MIN_M, M256_MAX_M = 129, 256
+
+
+def m256_supported(M: int, N: int, K: int) -> bool:
+    return M256_MIN_M <= M <= M256_MAX_M and N % 128 == 0 and N >= 128 and K % 64 == 0 and K >= 64
+
+
+def m256_linear(x: torch.Tensor, w: torch.Tensor, grid: int, full: int, tail_split: int,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_m256_gemm_nt with the plan (grid, full, tail_split)."""
+    out, M, N, K = _gemm_args(x, w, out)
+    ws = gemm_workspace(x.device)
+    check(
+        lib().msgl_m256_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                out.stride(0), _dt(x), grid, full, tail_split, ws.data_ptr(), ws.numel(), _stream()),
+        "m256_gemm_nt",
+    )
+    return out
+
+
+def m256_candidates(M: int, N: int, K: int, cus: int):
+    """(grid, full, tail_split) plans worth timing.  grid = CU count (one resident workgroup per CU); whole tiles
+    in rounds of `grid`, the remaining tiles cut into k-slices so that remainder x slices fills the grid; without a
+    whole round, k-slices so that tiles x slices is about one or two grids."""
+    tiles, nsteps = N // 128, K // 64
+    out = []
+
+    def add(full, split):
+        split = max(1, min(split, nsteps, 64))
+        if split > 1 and split * M * (tiles - full) * 128 * 4 > GEMM_WORKSPACE_BYTES:
+            return
+        if (cus, full, split) not in out:
+            out.append((cus, full, split))
+
+    full = tiles // cus * cus
+    rest = tiles - full
+    add(tiles, 1)                                    # every tile whole (rounds of `grid`)
+    if rest:
+        for div in (1, 2, 4):                        # remainder spread over all / half / a quarter of the grid
+            if cus // (rest * div) >= 2:
+                add(full, cus // (rest * div))
+    if full == 0:
+        for target in (cus, 2 * cus, 3 * cus):
+            add(0, target // tiles)
+            add(0, -(-target // tiles))
+    return out
+
+
+def m256_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) -> dict:
+    """Time the plans of m256_candidates on rotating weights and keep the fastest for this shape if it beats
+    `incumbent_us` (the best of the library and the other hand-written kernels) by PLAN_MARGIN."""
+    weights = list(weights)
+    w0 = weights[0]
+    M, K = x.shape
+    N = w0.shape[0]
+    res = dict(M=M, N=N, K=K, incumbent_us=incumbent_us, m256_us=None, plan=None, used=False)
+    if not m256_supported(M, N, K):
+        return res
+    cus = int(lib().msgl_device_cu_count())
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+
+    def time_us(plan, rounds):
+        m256_linear(x, w0, *plan, out=out)  # warm-up
+        ts = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(iters):
+                m256_linear(x, weights[(i + 1) % len(weights)], *plan, out=out)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / iters)
+        return min(ts)
+
+    cands = m256_candidates(M, N, K, cus)
+    ranked = sorted((time_us(p, 1), p) for p in cands)
+    best = min((time_us(p, 3), p) for _, p in ranked[:3])
+    res.update(m256_us=best[0], plan=best[1], all={"/".join(map(str, p)): round(t, 1) for t, p in ranked})
+    key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    if best[0] < PLAN_MARGIN * incumbent_us:
+        _M256_PLAN[key] = best[1]
+        res["used"] = True
+    else:
+        _M256_PLAN.pop(key, None)
+    return res
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M, N] = x[M, K] @ w[N, K]^T (the reference's `F.linear`, P/layers/linear.py:32): the hand-written
     weight-streaming kernel where skinny_tune() planned it (decode batches <= 64), else msgl_gemm_nt with the
@@ -530,6 +619,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     out, M, N, K = _gemm_args(x, w, out)
     if M == 0:
         return out
+    if M >= M256_MIN_M and _M256_PLAN:
+        plan = _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return m256_linear(x, w, plan[0], plan[1], plan[2], out)
     if M <= WSTREAM_MAX_M and _WSTREAM_PLAN:
         plan = _WSTREAM_PLAN.get((M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:

@@ -195,3 +195,69 @@ def test_wstream_gemm_rejects_what_it_cannot_do(ops, dev):
         ops.wstream_linear(x, w, 1, 5)  # more splits than 64-k steps
     with pytest.raises(RuntimeError):
         ops.wstream_linear(torch.zeros((257, 256), dtype=torch.bfloat16, device=dev), w, 1, 1)
+
+
+# ---------------------------------------------------------------- full decode batches: LDS-DMA ring, 32x32x16 (M <= 256)
+@pytest.mark.parametrize("M", [129, 200, 256])
+@pytest.mark.parametrize("N,K", [(5120, 5120), (7168, 5120), (128, 64), (1024, 17408), (2304, 640), (34816, 1024)])
+def test_m256_gemm_matches_fp32_reference(ops, dev, M, N, K):
+    """Every kind of plan: all tiles whole (several rounds per workgroup), whole tiles + k-sliced remainder, pure
+    k-slicing incl. ragged slices and more units than workgroups; padded x rows (M < 256).  Slabs are added in
+    slice order => bitwise repeatable."""
+    g = torch.Generator(device=dev).manual_seed(M * 31 + N + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    ref = _ref(x, w)
+    assert ops.m256_supported(M, N, K)
+    tiles, nsteps = N // 128, K // 64
+    plans = set(ops.m256_candidates(M, N, K, 256))
+    plans |= {(8, tiles, 1), (8, 0, min(3, nsteps)), (256, tiles // 2, min(2, nsteps)), (3, max(tiles - 1, 0), min(5, nsteps))}
+    for grid, full, split in sorted(plans):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.m256_linear(x, w, grid, full, split, out=out)
+        _check(out, ref)
+        assert torch.equal(out, ops.m256_linear(x, w, grid, full, split)), (grid, full, split)
+
+
+def test_m256_gemm_identity_and_asymmetric_operands(ops, dev):
+    """A = I with an asymmetric B catches a transposed accumulator write (cdna_hip_programming.md, section 3)."""
+    M, N, K = 256, 256, 256
+    x = torch.eye(K, dtype=torch.bfloat16, device=dev)[:M]
+    w = (torch.arange(N, device=dev)[:, None] * 0.25 + torch.arange(K, device=dev)[None, :] * 3.0).to(torch.bfloat16)
+    for plan in ((256, 2, 1), (256, 0, 2), (4, 1, 4)):
+        out = ops.m256_linear(x, w, *plan)
+        assert torch.equal(out.float(), w.float().t()[:M].contiguous()), plan
+
+
+def test_m256_gemm_fp16_strided_operands_and_dispatch(ops, dev):
+    g = torch.Generator(device=dev).manual_seed(11)
+    big = (torch.randn((200, 3 * 512), generator=g, device=dev) * 0.5).to(torch.float16)
+    x = big[:, 512:1024]
+    w_all = (torch.randn((768, 1024), generator=g, device=dev) * 0.05).to(torch.float16)
+    w = w_all[:, :512]
+    fused = torch.zeros((200, 2048), dtype=torch.float16, device=dev)
+    for plan in ((256, 6, 1), (256, 0, 4), (16, 4, 2)):
+        out = ops.m256_linear(x, w, *plan, out=fused[:, 256:1024])
+        _check(out, _ref(x, w))
+    assert fused[:, :256].abs().max().item() == 0 and fused[:, 1024:].abs().max().item() == 0
+    # ops.linear picks the planned kernel for the shape and nothing else
+    xb = (torch.randn((256, 640), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    wb = (torch.randn((2304, 640), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    rep = ops.m256_tune(xb, [wb], incumbent_us=1e9)
+    assert rep["used"] and rep["plan"] is not None
+    _check(ops.linear(xb, wb), _ref(xb, wb))
+    assert torch.equal(ops.linear(xb, wb), ops.m256_linear(xb, wb, *rep["plan"]))
+    ops._M256_PLAN.clear()
+
+
+def test_m256_gemm_rejects_what_it_cannot_do(ops, dev):
+    x = torch.zeros((256, 256), dtype=torch.bfloat16, device=dev)
+    w = torch.zeros((256, 256), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.m256_linear(x, torch.zeros((192, 256), dtype=torch.bfloat16, device=dev), 256, 1, 1)  # N % 128
+    with pytest.raises(RuntimeError):
+        ops.m256_linear(x, w, 256, 3, 1)      # more whole tiles than tiles
+    with pytest.raises(RuntimeError):
+        ops.m256_linear(x, w, 256, 0, 5)      # more k-slices than 64-k steps
+    with pytest.raises(RuntimeError):
+        ops.m256_linear(torch.zeros((257, 256), dtype=torch.bfloat16, device=dev), w, 256, 2, 1)
