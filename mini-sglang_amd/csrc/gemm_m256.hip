@@ -30,16 +30,10 @@ namespace msgl {
 typedef __attribute__((ext_vector_type(16))) float g2_f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 g2_bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 g2_f16x8;
-typedef __attribute__((address_space(3))) void g2_lds_void;
-typedef __attribute__((address_space(1))) const void g2_glb_void;
+typedef uint32_t G4 __attribute__((ext_vector_type(4)));  // 16 bytes in registers
 
-template <typename T, int ABL = 0>
+template <typename T>
 __device__ __forceinline__ g2_f32x16 g2_mfma(const U4& a, const U4& b, g2_f32x16 c) {
-  if constexpr ((ABL & 8) != 0) {  // ablation: consume the operands without the matrix pipe
-    c[0] += __uint_as_float((a.x ^ b.x) & 0x3f800000u);
-    c[1] += __uint_as_float((a.y ^ b.y ^ a.z ^ b.z ^ a.w ^ b.w) & 0x3f800000u);
-    return c;
-  }
   if constexpr (std::is_same_v<T, BF16>)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g2_bf16x8, a), __builtin_bit_cast(g2_bf16x8, b),
                                                    c, 0, 0, 0);
@@ -54,40 +48,37 @@ constexpr int kG2Rows = 256;                   // x rows per tile (M <= 256, row
 constexpr int kG2StepK = 64;
 constexpr int kG2XBytes = kG2Rows * 128;       // 32 KB
 constexpr int kG2WBytes = kG2TileN * 128;      // 16 KB
-constexpr int kG2XSlots = 2;                   // x tile of the step being read + the one landing
-constexpr int kG2WSlots = 5;                   // w tile being read + four in flight (64 KB of the weight stream per CU)
-constexpr int kG2WBase = kG2XSlots * kG2XBytes;
-constexpr int kG2LdsBytes = kG2WBase + kG2WSlots * kG2WBytes;  // 144 KB
+constexpr int kG2Stage = kG2XBytes + kG2WBytes;        // 48 KB
+constexpr int kG2LdsBytes = 2 * kG2Stage;               // double buffer (96 KB); also holds the staged output tile
 constexpr int kG2OutPitch = 264;               // bytes per row of the bf16 output tile staged in LDS (256 + 8)
 
 template <typename T, int ABL = 0>
 __global__ __launch_bounds__(kG2Threads) void m256_gemm_kernel(
     uint16_t* __restrict__ out, float* __restrict__ part, const uint16_t* __restrict__ x,
     const uint16_t* __restrict__ w, int M, int nsteps, int64_t ldx, int64_t ldw, int64_t ldo, int tiles, int full,
-    int tail_split, int64_t ld_part, int wpat) {
+    int tail_split, int64_t ld_part) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[kG2LdsBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = sgpr(tid >> 6);
   const int mi = wv >> 2, ni = wv & 3;
   const int j = lane & 31, h = lane >> 5;
 
-  // ---- DMA source offsets (bytes).  One wave instruction fills 1 KB = 8 rows x 128 B; lane -> (row, slot):
-  // row = 8 i + lane / 8, slot = lane % 8 holds global chunk slot ^ ((row >> 1) & 7).
-  // Waves 0-3 request the x tile (L2-resident, 8 pieces each), waves 4-7 the weight tile (HBM, 4 pieces each): loads
-  // return in order per wave, so a wave that mixed the two would see its L2 hits only after the HBM misses issued
-  // before them, and the x tiles would sit in the in-flight window for a full HBM latency.  Split by wave, x needs
-  // one step of lead and two slots, and the LDS that frees holds four weight tiles in flight.
-  const int drow = lane >> 3, dslot = lane & 7;
-  const bool x_role = wv < 4;
-  uint32_t doff[8];
+  // ---- staging map.  One wave load covers 8 rows x 128 B (whole lines): lane -> (row 8 i + lane / 8, chunk lane % 8);
+  // the chunk lands in LDS at slot chunk ^ ((row >> 1) & 7).  x tile: 32 wave loads (4 per wave), w tile: 16 (2 per wave).
+  const int drow = lane >> 3, dchunk = lane & 7;
+  uint32_t xoff[4], woff[2];   // global byte offsets (row part; + k bytes of the step)
+  int xl[4], wl[2];            // LDS byte offsets within a stage
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int row = x_role ? (wv * 8 + p) * 8 + drow : ((wv - 4) * 4 + (p & 3)) * 8 + drow;
-    const int chunk = dslot ^ ((row >> 1) & 7);
-    doff[p] = x_role ? (uint32_t)(min(row, M - 1) * (int)ldx * 2 + chunk * 16) : (uint32_t)(row * (int)ldw * 2 + chunk * 16);
-    if ((ABL & 32) && !x_role && wpat == 1)
-      doff[p] = (uint32_t)((((wv - 4) * 4 + (p & 3)) * 4 + (lane >> 4)) * (int)ldw * 2 + (lane & 15) * 16);
-    if ((ABL & 32) && !x_role && wpat == 2) doff[p] = (uint32_t)(((wv - 4) * 4 + (p & 3)) * 1024 + lane * 16);
+  for (int p = 0; p < 4; ++p) {
+    const int row = (wv * 4 + p) * 8 + drow;
+    xoff[p] = (uint32_t)(min(row, M - 1) * (int)ldx * 2 + dchunk * 16);
+    xl[p] = row * 128 + ((dchunk ^ ((row >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (wv * 2 + p) * 8 + drow;
+    woff[p] = (uint32_t)(row * (int)ldw * 2 + dchunk * 16);
+    wl[p] = kG2XBytes + row * 128 + ((dchunk ^ ((row >> 1) & 7)) * 16);
   }
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
 
@@ -96,112 +87,114 @@ __global__ __launch_bounds__(kG2Threads) void m256_gemm_kernel(
   int fo[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) fo[s] = ((2 * s + h) ^ swz) * 16;
-  const int a_row = (ni * 32 + j) * 128;               // weight fragment row (A operand), within a w slot
+  const int a_row = kG2XBytes + (ni * 32 + j) * 128;   // weight fragment row (A operand)
   const int b_row = (mi * 128 + j) * 128;              // x fragment row of block 0 (B operand); block b: + b * 32 * 128
 
-  // LDS-DMA by inline asm: hipcc does not see these as LDS writes, so it neither drains them with a vmcnt(0) in
-  // front of the next ds_read (it does for the builtin: every step would wait for the stage it just requested)
-  // nor counts them; the pipeline is counted by hand below (6 DMAs per wave and step).  saddr form: uniform
-  // 64-bit base in SGPRs + this lane's 32-bit byte offset; M0 = LDS byte address of the 1-KB piece.
-  auto dma = [&](const unsigned char* base, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr)
-                 : "memory", "m0");
+  struct Regs {
+    G4 x0, x1, x2, x3, w0, w1;
   };
-  const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto issue_x = [&](int step) {  // waves 0-3
+  auto load = [&](Regs& r, const unsigned char* wt, int step) __attribute__((always_inline)) {
     const int64_t kb = (int64_t)step * (kG2StepK * 2);
-    const uint32_t sb = smem_base + (step & 1) * kG2XBytes + wv * 8192;
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-      if (!(ABL & 1)) dma(xb + kb, doff[p], sb + p * 1024);
-  };
-  auto issue_w = [&](const unsigned char* wt, int step, int slot) {  // waves 4-7
-    int64_t kb = (int64_t)step * (kG2StepK * 2);
-    if (ABL & 32) {  // streaming-pattern probe (data unused): 1 = 4 rows x 256 B per piece, 2 = contiguous 16-KB tiles
-      if (wpat == 1) kb = (int64_t)(step >> 1) * 256 + (int64_t)(step & 1) * 64 * ldw * 2;
-      if (wpat == 2) kb = (int64_t)step * kG2WBytes;
+    if (!(ABL & 1)) {
+      r.x0 = *reinterpret_cast<const G4*>(xb + kb + xoff[0]);
+      r.x1 = *reinterpret_cast<const G4*>(xb + kb + xoff[1]);
+      r.x2 = *reinterpret_cast<const G4*>(xb + kb + xoff[2]);
+      r.x3 = *reinterpret_cast<const G4*>(xb + kb + xoff[3]);
     }
-    const uint32_t sb = smem_base + kG2WBase + slot * kG2WBytes + (wv - 4) * 4096;
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      if (!(ABL & 4)) dma(wt + kb, doff[p], sb + p * 1024);
+    if (!(ABL & 4)) {
+      if (ABL & 8) {  // probe: non-temporal weight loads
+        r.w0 = __builtin_nontemporal_load(reinterpret_cast<const G4*>(wt + kb + woff[0]));
+        r.w1 = __builtin_nontemporal_load(reinterpret_cast<const G4*>(wt + kb + woff[1]));
+      } else {
+        r.w0 = *reinterpret_cast<const G4*>(wt + kb + woff[0]);
+        r.w1 = *reinterpret_cast<const G4*>(wt + kb + woff[1]);
+      }
+    }
+  };
+  auto store = [&](const Regs& r, int buf) __attribute__((always_inline)) {
+    unsigned char* sb = smem + buf * kG2Stage;
+    if (!(ABL & 1)) {
+      *reinterpret_cast<G4*>(sb + xl[0]) = r.x0;
+      *reinterpret_cast<G4*>(sb + xl[1]) = r.x1;
+      *reinterpret_cast<G4*>(sb + xl[2]) = r.x2;
+      *reinterpret_cast<G4*>(sb + xl[3]) = r.x3;
+    }
+    if (!(ABL & 4)) {
+      *reinterpret_cast<G4*>(sb + wl[0]) = r.w0;
+      *reinterpret_cast<G4*>(sb + wl[1]) = r.w1;
+    }
   };
 
   // one segment: tile `tile`, steps [s0, s1); partial => fp32 slab `slice`, else bf16 out
-  auto segment = [&](int tile, int s0, int s1, bool partial, int slice) {
+  auto segment = [&](int tile, int s0, int s1, bool partial, int slice) __attribute__((always_inline)) {
     const unsigned char* wt = reinterpret_cast<const unsigned char*>(w) + (int64_t)tile * kG2TileN * ldw * 2;
-    if ((ABL & 32) && wpat == 2) wt = reinterpret_cast<const unsigned char*>(w) + (int64_t)tile * nsteps * kG2WBytes;
     g2_f32x16 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
-
-    // x slot of step t: t & 1 (absolute parity: consecutive segments keep alternating); w slot: ring position
-    if (x_role) {
-      issue_x(s0);
-    } else {
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-        if (s0 + d < s1) issue_w(wt, s0 + d, d);
-    }
-    int wslot = 0;
-    // Software pipeline across the step boundary: the MFMAs of the LAST sub-step of step t - 1 (operands already
-    // in registers) run after the barrier of step t, behind the first fragment reads of step t, so the LDS
-    // latency at a step start is covered by MFMA work instead of idling the pipe; inside a step the x fragments
-    // of sub-step s + 1 are requested before the MFMAs of sub-step s.  sched_barrier pins that order (the
-    // compiler otherwise sinks every read to just before its use to save registers).
     U4 a[4], bc[4], bn[4];
-    U4 pa = U4{0, 0, 0, 0}, pb[4] = {pa, pa, pa, pa};  // deferred sub-step: zeros => adds nothing the first time
-    for (int t = s0; t < s1; ++t) {
-      // step t's tiles landed (this wave's share: counted wait; everyone's: the barrier).  The barrier also says
-      // every wave is done READING step t - 1's tiles, whose slots are refilled right after it.
-      if (x_role) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        const int ahead = min(3, s1 - 1 - t);  // weight tiles issued after step t's: 4 pieces each
-        if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 4) ? 0 : 12) : "memory");
-        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 4) ? 0 : 8) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 4) ? 0 : 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      if (x_role) {
-        if (t + 1 < s1) issue_x(t + 1);
-      } else {
-        if (t + 4 < s1) issue_w(wt, t + 4, wslot == 0 ? 4 : wslot - 1);
-      }
-      const unsigned char* sx = smem + (t & 1) * kG2XBytes;
-      const unsigned char* sw = smem + kG2WBase + wslot * kG2WBytes;
-      wslot = wslot == 4 ? 0 : wslot + 1;
-      if (ABL & 2) continue;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bc[b] = (ABL & 16) ? U4{(uint32_t)t, 1, 2, 3} : *reinterpret_cast<const U4*>(sx + b_row + b * (32 * 128) + fo[0]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) a[s] = (ABL & 16) ? U4{(uint32_t)t, 5, 6, 7} : *reinterpret_cast<const U4*>(sw + a_row + fo[s]);
+    U4 pa = U4{0, 0, 0, 0}, pb[4] = {pa, pa, pa, pa};  // deferred sub-step: zeros add nothing the first time
+
+    // One step.  On entry: LDS stage `buf` holds tile `step` (visible to all), `have` holds tile step + 1 (requested one
+    // step ago).  Request tile step + 2 into `next`; read the first fragments of this tile; run the MFMAs of the LAST
+    // sub-step of the previous tile (operands kept in registers across the barrier) behind those reads; then sub-steps
+    // 0..2 with the fragments of sub-step s + 1 requested before the MFMAs of sub-step s; publish tile step + 1 to the
+    // other stage (nobody reads it any more: every wave passed the barrier that ended step - 1); barrier.
+    // sched_barrier pins the order: left alone the compiler sinks each read to just before its use (MFMA pipe starved).
+    auto body = [&](int buf, int step, const Regs& have, Regs& next) __attribute__((always_inline)) {
+      load(next, wt, min(step + 2, s1 - 1));
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 2)) {
+        const unsigned char* sb = smem + buf * kG2Stage;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] = g2_mfma<T, ABL>(pa, pb[b], acc[b]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < 4; ++b) bc[b] = *reinterpret_cast<const U4*>(sb + b_row + b * (32 * 128) + fo[0]);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) bn[b] = (ABL & 16) ? U4{(uint32_t)t, 9, 8, 7} : *reinterpret_cast<const U4*>(sx + b_row + b * (32 * 128) + fo[s + 1]);
+        for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const U4*>(sb + a_row + fo[s]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = g2_mfma<T, ABL>(a[s], bc[b], acc[b]);
+        for (int b = 0; b < 4; ++b) acc[b] = g2_mfma<T>(pa, pb[b], acc[b]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bc[b] = bn[b];
-      }
-      pa = a[3];
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) pb[b] = bc[b];
+          for (int b = 0; b < 4; ++b) bn[b] = *reinterpret_cast<const U4*>(sb + b_row + b * (32 * 128) + fo[s + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[b] = g2_mfma<T>(a[s], bc[b], acc[b]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) bc[b] = bn[b];
+        }
+        pa = a[3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pb[b] = bc[b];
+      }
+      store(have, buf ^ 1);
+      __syncthreads();
+    };
+
+    {
+      Regs ra = {}, rb = {};
+      load(ra, wt, s0);
+      load(rb, wt, min(s0 + 1, s1 - 1));
+      store(ra, 0);
+      __syncthreads();
+      int t = s0;
+      for (; t + 2 <= s1; t += 2) {
+        body(0, t, rb, ra);
+        body(1, t + 1, ra, rb);
+      }
+      if (t < s1) body(0, t, rb, ra);
     }
+    if (!(ABL & 2)) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = g2_mfma<T, ABL>(pa, pb[b], acc[b]);
+      for (int b = 0; b < 4; ++b) acc[b] = g2_mfma<T>(pa, pb[b], acc[b]);
+    }
 
     // ---- epilogue.  Lane holds D[n = 32 ni + 8 g + 4 h + e][m = 128 mi + 32 b + j], g = reg >> 2, e = reg & 3.
+    // (every wave is past the barrier that ended the last step: both stages are free)
     if (partial) {
       const int64_t col = (int64_t)(tile - full) * kG2TileN + ni * 32 + 4 * h;
 #pragma unroll
@@ -217,9 +210,7 @@ __global__ __launch_bounds__(kG2Threads) void m256_gemm_kernel(
           }
         }
       }
-      __builtin_amdgcn_s_barrier();  // all waves out of the k loop before the next segment refills stage 0
     } else {
-      __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: LDS becomes the output tile
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         unsigned char* row = smem + (mi * 128 + b * 32 + j) * kG2OutPitch + (ni * 32 + 4 * h) * 2;
@@ -242,7 +233,7 @@ __global__ __launch_bounds__(kG2Threads) void m256_gemm_kernel(
           *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + (int64_t)tile * kG2TileN + c8 * 4) = v;
         }
       }
-      __syncthreads();  // the output tile is read out before the next segment's DMAs land on it
+      __syncthreads();  // the output tile is read out before the next segment stages into it
     }
   };
 
@@ -286,21 +277,17 @@ static int launch_m256(uint16_t* out, float* part, const uint16_t* x, const uint
                        int64_t ldx, int64_t ldw, int64_t ldo, int grid, int full, int tail_split, hipStream_t s) {
   const int tiles = N / kG2TileN, nsteps = K / kG2StepK;
   const int64_t width = (int64_t)(tiles - full) * kG2TileN;
-  static const int abl = getenv("MSGL_M256_ABLATE") ? atoi(getenv("MSGL_M256_ABLATE")) : 0;
-  static const int wpat = getenv("MSGL_M256_WPAT") ? atoi(getenv("MSGL_M256_WPAT")) : 0;
+  static const int abl = getenv("MSGL_M256_ABLATE") ? atoi(getenv("MSGL_M256_ABLATE")) : 0;  // diagnosis only
 #define MSGL_G2(A)                                                                                              \
   m256_gemm_kernel<T, A><<<dim3((unsigned)grid), dim3(kG2Threads), 0, s>>>(out, part, x, w, M, nsteps, ldx, ldw, \
-                                                                          ldo, tiles, full, tail_split, width, wpat)
+                                                                          ldo, tiles, full, tail_split, width)
   switch (abl) {
-    case 1: MSGL_G2(1); break;
     case 2: MSGL_G2(2); break;
     case 3: MSGL_G2(3); break;
-    case 4: MSGL_G2(4); break;
     case 5: MSGL_G2(5); break;
     case 6: MSGL_G2(6); break;
-    case 13: MSGL_G2(13); break;
-    case 21: MSGL_G2(21); break;
-    case 35: MSGL_G2(35); break;
+    case 8: MSGL_G2(8); break;
+    case 11: MSGL_G2(11); break;
     default: MSGL_G2(0); break;
   }
 #undef MSGL_G2

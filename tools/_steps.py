@@ -2,8 +2,9 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mini_sglang_amd import ops
 dev = torch.device("cuda:0")
-def t_us(fn, iters=20):
-    fn(); torch.cuda.synchronize()
+def t_us(fn, iters=300):
+    for _ in range(300): fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): fn()
