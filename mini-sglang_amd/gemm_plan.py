@@ -9,6 +9,7 @@ benchmarked path and the drop-in path choose kernels the same way.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -51,7 +52,7 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r["skinny_used"] = True  # reported as hand-written by bench.py
                     r["kernel"] = (f"msgl::wstream_gemm_kernel[row tiles {wsr['row_tiles']}, "
                                    f"k splits {wsr['k_splits']}]")
-            if ops.m256_supported(bs, r["N"], r["K"]):  # one workgroup per CU, LDS-DMA ring (gemm_m256.hip)
+            if ops.m256_supported(bs, r["N"], r["K"]) and os.environ.get("MSGL_DISABLE_M256") != "1":  # one workgroup per CU, LDS-DMA ring (gemm_m256.hip)
                 mr = ops.m256_tune(x, ws, r["best_us"])
                 r.update(m256_us=mr["m256_us"], m256_plan=mr["plan"], m256_used=mr["used"], m256_all=mr.get("all"))
                 if mr["used"]:

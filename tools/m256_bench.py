@@ -21,8 +21,9 @@ from mini_sglang_amd._lib import lib  # noqa: E402
 from mini_sglang_amd.model import PRESETS  # noqa: E402
 
 
-def time_us(fn, weights, iters=10, rounds=3):
-    fn(weights[0])
+def time_us(fn, weights, iters=20, rounds=3, warm=40):
+    for i in range(warm):  # clocks ramp over milliseconds: time at the sustained state
+        fn(weights[i % len(weights)])
     best = 1e30
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
