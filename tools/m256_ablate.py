@@ -1,3 +1,9 @@
+"""Per-step cost of the full-batch projection kernel under its ablation switches (profiles/r02b_m256_gemm_ablation.txt).
+
+    MSGL_M256_ABLATE=<bits> python tools/m256_ablate.py     bits: 1 no x loads, 2 no compute, 4 no w loads, 8 nt w loads
+
+N = 32768 (one whole tile per workgroup), K = 5120 and 10240: the difference gives the cost of 80 steps.
+"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mini_sglang_amd import ops
