@@ -256,6 +256,28 @@ int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M, int N, int
                       int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Peer-to-peer collectives over xGMI for decode-size messages (libmsgl_hip.so, csrc/comm_p2p.hip).
+ * What the reference gets from its symmetric buffer (ncclMemAlloc + ncclCommWindowRegister(
+ * NCCL_WIN_COLL_SYMMETRIC), C/src/pynccl.cu:81-90) and NCCL's symmetric kernels (all_reduce through the
+ * window for messages <= max_bytes, pynccl.cu:105-123): every rank owns one fine-grained buffer, all ranks
+ * map all buffers (hipIpc), one kernel per collective reads the peers directly: one-shot below
+ * `one_shot_max_bytes`, reduce-scatter + all-gather (all links at once) above.  In place, SUM in rank order
+ * (identical bits on every rank), capturable, never synchronises; bounded spins (msgl_p2p_error).
+ * Set-up: create -> exchange msgl_p2p_ipc_handle bytes over the host's CPU group -> open. */
+#define MSGL_IPC_HANDLE_BYTES 64
+typedef struct msgl_p2p* msgl_p2p_t;
+int msgl_p2p_create(msgl_p2p_t* out, int rank, int world_size, size_t max_bytes);
+int msgl_p2p_ipc_handle(msgl_p2p_t comm, void* out_handle /* MSGL_IPC_HANDLE_BYTES */);
+int msgl_p2p_open(msgl_p2p_t comm, const void* all_handles /* world_size x MSGL_IPC_HANDLE_BYTES, rank order */);
+int msgl_p2p_configure(msgl_p2p_t comm, size_t one_shot_max_bytes, int blocks);
+int msgl_p2p_all_reduce_sum(msgl_p2p_t comm, void* data, size_t count, int dtype, void* stream);
+int msgl_p2p_all_gather(msgl_p2p_t comm, void* dst, const void* src, size_t count, int dtype, void* stream);
+int msgl_p2p_error(msgl_p2p_t comm);
+void* msgl_p2p_get_buffer(msgl_p2p_t comm);
+int msgl_p2p_destroy(msgl_p2p_t comm);   /* detaches; buffers stay mapped until msgl_p2p_release_all / exit */
+int msgl_p2p_release_all(void);
+
+/* ------------------------------------------------------------------------
  * Tensor-parallel communicator over RCCL (libmsgl_comm.so).  Replaces
  * NCCLWrapper (C/src/pynccl.cu:72-175) / init_pynccl (P/kernel/pynccl.py:47-78).
  * ---------------------------------------------------------------------- */

@@ -22,6 +22,7 @@ GEMM_SO = LIB_DIR / "libmsgl_gemm.so"
 
 BF16, FP16, F32 = 0, 1, 2
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 PREFILL_QTILE = 128
 ABI_VERSION = 3
 
@@ -63,6 +64,16 @@ HIP_SIGNATURES = {
     "msgl_skinny_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
     "msgl_wstream_gemm_workspace_bytes": (_l, [_i, _i, _i]),
     "msgl_wstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _l, _p]),
+    "msgl_p2p_create": (_i, [C.POINTER(_p), _i, _i, _sz]),
+    "msgl_p2p_ipc_handle": (_i, [_p, C.c_char_p]),
+    "msgl_p2p_open": (_i, [_p, C.c_char_p]),
+    "msgl_p2p_configure": (_i, [_p, _sz, _i]),
+    "msgl_p2p_all_reduce_sum": (_i, [_p, _p, _sz, _i, _p]),
+    "msgl_p2p_all_gather": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "msgl_p2p_error": (_i, [_p]),
+    "msgl_p2p_get_buffer": (_p, [_p]),
+    "msgl_p2p_destroy": (_i, [_p]),
+    "msgl_p2p_release_all": (_i, []),
     "msgl_m256_gemm_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "msgl_m256_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
 }

@@ -37,6 +37,7 @@ HIP_SOURCES = [
     "gemm_skinny.hip",
     "gemm_wstream.hip",
     "gemm_m256.hip",
+    "comm_p2p.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]
 GEMM_SOURCES = ["gemm.cpp"]

@@ -1,0 +1,340 @@
+// Peer-to-peer collectives over xGMI for decode-size messages.
+//
+// The reference stages messages <= max_bytes through a symmetric buffer (ncclMemAlloc +
+// ncclCommWindowRegister(NCCL_WIN_COLL_SYMMETRIC), C/src/pynccl.cu:81-90, 105-123) so that NCCL's symmetric
+// kernels can read the peers' copies directly.  The MI355X equivalent written out: every rank owns one buffer of
+// fine-grained (uncached) device memory, all ranks map all buffers (hipIpc; xGMI peer access), and ONE kernel per
+// collective does the whole exchange with direct loads from the peers:
+//
+//   one-shot  (small messages): copy in -> flag barrier -> every rank sums all peers' copies in rank order
+//   two-shot  (larger):         copy in -> barrier -> rank r reduces chunk r from all peers into its own result
+//                               area -> barrier -> every rank gathers the reduced chunks from their owners
+//   all-gather:                 copy in -> barrier -> read every peer's copy
+//
+// xGMI is point to point (7 links per GPU): a ring all-reduce is bound by one link (2 (n-1)/n N / 153 GB/s), the
+// two-shot exchange drives all links at once (~2 N / n per link); at the 0.5-4 MB messages of a decode step the rest
+// is latency, which is one kernel and two or three flag round trips here.
+//
+// Rules: sums are taken in rank order 0..n-1 by every reader => all ranks hold identical bits (the replicated
+// schedulers and samplers of the ranks must not diverge); flags are monotonically increasing sequence numbers kept
+// in device memory (no host state changes per call => capturable in a hipGraph); a block synchronises only with
+// the same block index on the peers, and the copy-in / reduce / gather partitions are chosen so that block b only
+// ever reads what the peers' block b wrote; spin loops are bounded (error flag instead of a hung GPU).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+
+namespace msgl {
+
+constexpr int kP2PMaxRanks = 8;
+constexpr int kP2PMaxBlocks = 64;
+constexpr int kP2PThreads = 512;
+constexpr int kP2PPhases = 3;
+constexpr int kP2PHeaderBytes = 16384;
+constexpr uint32_t kP2PSpinLimit = 40u * 1000u * 1000u;
+
+struct P2PHeader {  // at offset 0 of every rank's buffer; flags are written by the peers
+  uint32_t flag[kP2PMaxBlocks][kP2PPhases][kP2PMaxRanks];
+  uint32_t seq[kP2PMaxBlocks][kP2PPhases];  // this rank's barrier counters (local)
+  uint32_t error;
+};
+static_assert(sizeof(P2PHeader) <= kP2PHeaderBytes, "header");
+
+struct P2PPeers {
+  unsigned char* base[kP2PMaxRanks];  // mapped buffers, [rank]
+};
+
+__device__ __forceinline__ void p2p_barrier(const P2PPeers& peers, int rank, int world, int phase, bool release) {
+  P2PHeader* self = reinterpret_cast<P2PHeader*>(peers.base[rank]);
+  const int b = blockIdx.x;
+  __syncthreads();  // everything this block did before the barrier is issued
+  if (release) __threadfence_system();
+  uint32_t seq = 0;
+  if (threadIdx.x < world) {
+    seq = self->seq[b][phase] + 1;  // every lane < world reads the same value
+    P2PHeader* peer = reinterpret_cast<P2PHeader*>(peers.base[threadIdx.x]);
+    __hip_atomic_store(&peer->flag[b][phase][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&self->flag[b][phase][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kP2PSpinLimit) {
+        __hip_atomic_store(&self->error, 1u + (uint32_t)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) self->seq[b][phase] = seq;
+}
+
+template <typename T>
+__device__ __forceinline__ void acc8(float (&a)[8], const U4& v) {
+  a[0] += Elem<T>::lo(v.x); a[1] += Elem<T>::hi(v.x); a[2] += Elem<T>::lo(v.y); a[3] += Elem<T>::hi(v.y);
+  a[4] += Elem<T>::lo(v.z); a[5] += Elem<T>::hi(v.z); a[6] += Elem<T>::lo(v.w); a[7] += Elem<T>::hi(v.w);
+}
+template <typename T>
+__device__ __forceinline__ U4 pack8f(const float (&a)[8]) {
+  U4 u;
+  u.x = Elem<T>::pack(a[0], a[1]); u.y = Elem<T>::pack(a[2], a[3]);
+  u.z = Elem<T>::pack(a[4], a[5]); u.w = Elem<T>::pack(a[6], a[7]);
+  return u;
+}
+
+// slice b of [0, n): contiguous, 16-byte packs
+__device__ __forceinline__ void block_slice(int64_t n, int64_t& lo, int64_t& hi) {
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  lo = min((int64_t)blockIdx.x * per, n);
+  hi = min(lo + per, n);
+}
+
+// data: in place, `packs` x 16 B.  area A (copy of the input) at base + header, area B (two-shot results) behind it.
+template <typename T, bool TWO_SHOT>
+__global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers peers, int rank, int world, U4* data,
+                                                                     int64_t packs, int64_t area_packs) {
+  U4* mine = reinterpret_cast<U4*>(peers.base[rank] + kP2PHeaderBytes);
+  if constexpr (!TWO_SHOT) {
+    int64_t lo, hi;
+    block_slice(packs, lo, hi);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) mine[i] = data[i];
+    p2p_barrier(peers, rank, world, 0, true);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) {
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = 0; r < world; ++r) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes)[i]);
+      data[i] = pack8f<T>(a);
+    }
+    p2p_barrier(peers, rank, world, 1, false);  // nobody refills its copy while a peer still reads it
+  } else {
+    const int64_t chunk = (packs + world - 1) / world;  // packs per owner
+    // copy in: for every chunk c this block's slice of c (what the peers' block b will read from me)
+    for (int c = 0; c < world; ++c) {
+      const int64_t c0 = min((int64_t)c * chunk, packs), cn = min(chunk, packs - c0);
+      int64_t lo, hi;
+      block_slice(cn, lo, hi);
+      for (int64_t i = c0 + lo + threadIdx.x; i < c0 + hi; i += kP2PThreads) mine[i] = data[i];
+    }
+    p2p_barrier(peers, rank, world, 0, true);
+    // reduce-scatter: my chunk, summed in rank order, into my result area
+    const int64_t m0 = min((int64_t)rank * chunk, packs), mn = min(chunk, packs - m0);
+    int64_t lo, hi;
+    block_slice(mn, lo, hi);
+    U4* res = mine + area_packs;
+    for (int64_t i = m0 + lo + threadIdx.x; i < m0 + hi; i += kP2PThreads) {
+      float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int r = 0; r < world; ++r) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes)[i]);
+      res[i] = pack8f<T>(a);
+    }
+    p2p_barrier(peers, rank, world, 1, true);
+    // all-gather of the reduced chunks from their owners
+    for (int c = 0; c < world; ++c) {
+      const int64_t c0 = min((int64_t)c * chunk, packs), cn = min(chunk, packs - c0);
+      int64_t l2, h2;
+      block_slice(cn, l2, h2);
+      const U4* src = reinterpret_cast<const U4*>(peers.base[c] + kP2PHeaderBytes) + area_packs;
+      for (int64_t i = c0 + l2 + threadIdx.x; i < c0 + h2; i += kP2PThreads) data[i] = src[i];
+    }
+    p2p_barrier(peers, rank, world, 2, false);
+  }
+}
+
+// dst[r * packs + i] = src_of_rank_r[i]
+__global__ __launch_bounds__(kP2PThreads) void p2p_all_gather_kernel(P2PPeers peers, int rank, int world, U4* dst,
+                                                                     const U4* src, int64_t packs) {
+  U4* mine = reinterpret_cast<U4*>(peers.base[rank] + kP2PHeaderBytes);
+  int64_t lo, hi;
+  block_slice(packs, lo, hi);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) mine[i] = src[i];
+  p2p_barrier(peers, rank, world, 0, true);
+  for (int r = 0; r < world; ++r) {
+    const U4* from = reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) dst[(int64_t)r * packs + i] = from[i];
+  }
+  p2p_barrier(peers, rank, world, 1, false);
+}
+
+}  // namespace msgl
+
+using namespace msgl;
+
+struct msgl_p2p {
+  int rank = 0, world = 1;
+  size_t max_bytes = 0;        // largest message (each of the two data areas holds this much)
+  size_t total_bytes = 0;
+  void* local = nullptr;       // this rank's buffer
+  void* mapped[kP2PMaxRanks] = {nullptr};
+  bool opened[kP2PMaxRanks] = {false};
+  hipIpcMemHandle_t handle;
+  P2PPeers peers;
+  size_t one_shot_max = 256 << 10;
+  int blocks = 32;
+};
+
+#define P2P_HIP(call, what)                                                     \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      ::msgl::set_error("%s: %s", what, hipGetErrorString(e_));                 \
+      (void)hipGetLastError();                                                  \
+      return MSGL_ELAUNCH;                                                      \
+    }                                                                           \
+  } while (0)
+
+extern "C" int msgl_p2p_create(msgl_p2p_t* out, int rank, int world_size, size_t max_bytes) {
+  MSGL_REQUIRE(out, "p2p_create: null pointer");
+  MSGL_REQUIRE(world_size >= 1 && world_size <= kP2PMaxRanks && rank >= 0 && rank < world_size,
+               "p2p_create: rank %d of %d (at most %d ranks)", rank, world_size, kP2PMaxRanks);
+  MSGL_REQUIRE(max_bytes >= 16 && max_bytes <= ((size_t)1 << 31), "p2p_create: max_bytes %zu", max_bytes);
+  msgl_p2p* c = new msgl_p2p();
+  c->rank = rank;
+  c->world = world_size;
+  c->max_bytes = (max_bytes + 4095) / 4096 * 4096;
+  c->total_bytes = kP2PHeaderBytes + 2 * c->max_bytes;
+  // fine-grained device memory: peers' loads and this rank's flag polls see stores without cache maintenance
+  hipError_t e = hipExtMallocWithFlags(&c->local, c->total_bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    set_error("p2p_create: hipExtMallocWithFlags(%zu, uncached): %s", c->total_bytes, hipGetErrorString(e));
+    (void)hipGetLastError();
+    delete c;
+    return MSGL_ELAUNCH;
+  }
+  if (hipMemset(c->local, 0, c->total_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+      hipIpcGetMemHandle(&c->handle, c->local) != hipSuccess) {
+    set_error("p2p_create: memset / ipc handle: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(c->local);
+    delete c;
+    return MSGL_ELAUNCH;
+  }
+  for (int r = 0; r < kP2PMaxRanks; ++r) c->peers.base[r] = nullptr;
+  c->mapped[rank] = c->local;
+  c->peers.base[rank] = static_cast<unsigned char*>(c->local);
+  *out = c;
+  return MSGL_OK;
+}
+
+extern "C" int msgl_p2p_ipc_handle(msgl_p2p_t c, void* out_handle) {
+  MSGL_REQUIRE(c && out_handle, "p2p_ipc_handle: null pointer");
+  memcpy(out_handle, &c->handle, sizeof(hipIpcMemHandle_t));
+  return MSGL_OK;
+}
+
+// all_handles: world x MSGL_IPC_HANDLE_BYTES, rank order (gathered by the host over its CPU group)
+extern "C" int msgl_p2p_open(msgl_p2p_t c, const void* all_handles) {
+  MSGL_REQUIRE(c && all_handles, "p2p_open: null pointer");
+  static_assert(sizeof(hipIpcMemHandle_t) == MSGL_IPC_HANDLE_BYTES, "ipc handle size");
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char*>(all_handles) + (size_t)r * MSGL_IPC_HANDLE_BYTES, sizeof(h));
+    void* p = nullptr;
+    P2P_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), "p2p_open: hipIpcOpenMemHandle");
+    c->mapped[r] = p;
+    c->opened[r] = true;
+    c->peers.base[r] = static_cast<unsigned char*>(p);
+  }
+  return MSGL_OK;
+}
+
+extern "C" int msgl_p2p_configure(msgl_p2p_t c, size_t one_shot_max_bytes, int blocks) {
+  MSGL_REQUIRE(c, "p2p_configure: null pointer");
+  MSGL_REQUIRE(blocks >= 1 && blocks <= kP2PMaxBlocks, "p2p_configure: blocks %d (1..%d)", blocks, kP2PMaxBlocks);
+  c->one_shot_max = one_shot_max_bytes;
+  c->blocks = blocks;
+  return MSGL_OK;
+}
+
+static int p2p_ready(msgl_p2p_t c, const char* what) {
+  for (int r = 0; r < c->world; ++r)
+    if (!c->peers.base[r]) {
+      set_error("%s: peer %d is not mapped (msgl_p2p_open not called)", what, r);
+      return MSGL_EINVAL;
+    }
+  return MSGL_OK;
+}
+
+extern "C" int msgl_p2p_all_reduce_sum(msgl_p2p_t c, void* data, size_t count, int dtype, void* stream) {
+  MSGL_REQUIRE(c && data, "p2p_all_reduce: null pointer");
+  MSGL_REQUIRE(dtype == MSGL_BF16 || dtype == MSGL_FP16, "p2p_all_reduce: dtype code %d unsupported", dtype);
+  if (count == 0) return MSGL_OK;
+  const size_t bytes = count * 2;
+  MSGL_REQUIRE(bytes % 16 == 0 && aligned16(data), "p2p_all_reduce: %zu bytes must be a multiple of 16, 16-byte aligned",
+               bytes);
+  MSGL_REQUIRE(bytes <= c->max_bytes, "p2p_all_reduce: %zu bytes exceed the buffer (%zu)", bytes, c->max_bytes);
+  if (int rc = p2p_ready(c, "p2p_all_reduce")) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t packs = (int64_t)(bytes / 16), area = (int64_t)(c->max_bytes / 16);
+  const bool two = bytes > c->one_shot_max && c->world > 1;
+  const dim3 grid((unsigned)c->blocks), block(kP2PThreads);
+#define MSGL_P2P(T, TWO) p2p_all_reduce_kernel<T, TWO><<<grid, block, 0, s>>>(c->peers, c->rank, c->world, (U4*)data, packs, area)
+  if (dtype == MSGL_BF16) { if (two) MSGL_P2P(BF16, true); else MSGL_P2P(BF16, false); }
+  else { if (two) MSGL_P2P(FP16, true); else MSGL_P2P(FP16, false); }
+#undef MSGL_P2P
+  MSGL_CHECK_LAUNCH("p2p_all_reduce");
+  return MSGL_OK;
+}
+
+extern "C" int msgl_p2p_all_gather(msgl_p2p_t c, void* dst, const void* src, size_t count, int dtype, void* stream) {
+  MSGL_REQUIRE(c && dst && src, "p2p_all_gather: null pointer");
+  MSGL_REQUIRE(dtype == MSGL_BF16 || dtype == MSGL_FP16, "p2p_all_gather: dtype code %d unsupported", dtype);
+  if (count == 0) return MSGL_OK;
+  const size_t bytes = count * 2;
+  MSGL_REQUIRE(bytes % 16 == 0 && aligned16(dst) && aligned16(src), "p2p_all_gather: %zu bytes per rank must be a "
+               "multiple of 16, 16-byte aligned", bytes);
+  MSGL_REQUIRE(bytes <= c->max_bytes, "p2p_all_gather: %zu bytes exceed the buffer (%zu)", bytes, c->max_bytes);
+  if (int rc = p2p_ready(c, "p2p_all_gather")) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  p2p_all_gather_kernel<<<dim3((unsigned)c->blocks), dim3(kP2PThreads), 0, s>>>(c->peers, c->rank, c->world, (U4*)dst,
+                                                                              (const U4*)src, (int64_t)(bytes / 16));
+  MSGL_CHECK_LAUNCH("p2p_all_gather");
+  return MSGL_OK;
+}
+
+// 0 = no barrier ever timed out; otherwise 1 + the phase that did (sticky).  Synchronises the device.
+extern "C" int msgl_p2p_error(msgl_p2p_t c) {
+  MSGL_REQUIRE(c, "p2p_error: null pointer");
+  uint32_t e = 0;
+  P2P_HIP(hipMemcpy(&e, &reinterpret_cast<P2PHeader*>(c->local)->error, sizeof(e), hipMemcpyDeviceToHost),
+          "p2p_error: read");
+  return (int)e;
+}
+
+extern "C" void* msgl_p2p_get_buffer(msgl_p2p_t c) {
+  return c ? static_cast<unsigned char*>(c->local) + kP2PHeaderBytes : nullptr;
+}
+
+// Buffers of destroyed communicators.  They are NOT unmapped / freed while the process lives: on this stack
+// (ROCm 7.0 runtime under PyTorch, dmabuf IPC) the first allocations made after hipIpcCloseMemHandle + hipFree of an
+// exported buffer were observed to read and write garbage (an engine built right after the communicator was destroyed
+// produced NaNs; the same engine built before, or with the release postponed, is bit-exact -- tests/test_gpu_tp.py).
+// A communicator lives as long as its engine and engines live as long as their process (the reference destroys its
+// NCCL wrapper at shutdown only, P/engine/engine.py:208-211), so parking a few MB until exit costs nothing.
+static std::vector<msgl_p2p*>& p2p_graveyard() {
+  static std::vector<msgl_p2p*>* g = new std::vector<msgl_p2p*>();
+  return *g;
+}
+
+extern "C" int msgl_p2p_destroy(msgl_p2p_t c) {
+  if (!c) return MSGL_OK;
+  (void)hipDeviceSynchronize();  // nothing of this communicator is in flight any more
+  for (int r = 0; r < kP2PMaxRanks; ++r) c->peers.base[r] = nullptr;  // any further collective is refused
+  p2p_graveyard().push_back(c);
+  return MSGL_OK;
+}
+
+// Unmap and free everything destroyed so far (call only when no further device allocation will be made, e.g.
+// right before process exit; never required).
+extern "C" int msgl_p2p_release_all(void) {
+  (void)hipDeviceSynchronize();
+  for (msgl_p2p* c : p2p_graveyard()) {
+    for (int r = 0; r < c->world; ++r)
+      if (c->opened[r] && c->mapped[r]) (void)hipIpcCloseMemHandle(c->mapped[r]);
+    if (c->local) (void)hipFree(c->local);
+    delete c;
+  }
+  p2p_graveyard().clear();
+  return MSGL_OK;
+}

@@ -86,7 +86,11 @@ class EngineConfig:
     max_seq_len_override: Optional[int] = None
     num_page_override: Optional[int] = None
     fused_qkv_path: bool = True
-    comm: Any = None  # RcclCommunicator (tp_size > 1)
+    comm: Any = None  # communicator with all_reduce / all_gather (tp_size > 1): kernel.init_pynccl(...)
+    comm_side: Any = None  # second communicator for side-stream collectives (see model.DenseDecoder.row_parallel)
+    comm_split_tokens: int = 0  # token-split + side-stream all-reduce for forwards of at least this many tokens
+    comm_overlap: bool = True
+    tp_cpu_group: Any = None  # torch.distributed CPU group of the TP ranks (pool sizing agreement)
     gemm_tune: str = "heuristic"  # "off" | "heuristic" | "full": library solution search per graph batch size
     seed: int = 42
 
@@ -205,11 +209,13 @@ class Engine:
 
         torch.cuda.synchronize(self.device)
         free_before = torch.cuda.mem_get_info(self.device)[0]
-        comm = Communicator(cfg.comm, cfg.tp_size)
+        free_before = self._agreed_free_memory(free_before)
+        comm = Communicator(cfg.comm, cfg.tp_size, side=cfg.comm_side)
         self.model = DenseDecoder(cfg.model, dtype=cfg.dtype, device=self.device, tp_rank=cfg.tp_rank,
-                                  tp_size=cfg.tp_size, seed=cfg.seed, comm=comm, fused=cfg.fused_qkv_path)
+                                  tp_size=cfg.tp_size, seed=cfg.seed, comm=comm, fused=cfg.fused_qkv_path,
+                                  comm_split_tokens=cfg.comm_split_tokens, comm_overlap=cfg.comm_overlap)
         torch.cuda.synchronize(self.device)
-        free_after = torch.cuda.mem_get_info(self.device)[0]
+        free_after = self._agreed_free_memory(torch.cuda.mem_get_info(self.device)[0])
 
         self.num_pages = determine_num_pages(free_before, free_after, cfg)
         num_tokens = self.num_pages * cfg.page_size
@@ -229,6 +235,22 @@ class Engine:
         # solution search happens before capture (it synchronises); full search only where it pays
         self.gemm_report = self.model.tune_gemms(bs_list, cfg.gemm_tune)
         self.graph_runner = GraphRunner(self, bs_list)
+
+    def _agreed_free_memory(self, free: int) -> int:
+        """Every TP rank must derive the same num_pages / max_seq_len / page-table width (the schedulers are
+        replicated): take the MIN of the ranks' free memory over the CPU group and refuse an imbalance above 2 GiB,
+        as _sync_get_memory does (P/engine/engine.py:170-189)."""
+        cfg = self.cfg
+        if cfg.tp_size == 1 or cfg.tp_cpu_group is None:
+            return free
+        import torch.distributed as dist
+
+        t = torch.tensor([free, -free], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=cfg.tp_cpu_group)
+        lo, hi = int(t[0]), -int(t[1])
+        if hi - lo > 2 * 1024 ** 3:
+            raise RuntimeError(f"Memory across TP ranks are imbalanced: min {lo / 2**30:.2f} GiB, max {hi / 2**30:.2f} GiB")
+        return lo
 
     def forward_batch(self, batch: Batch, args: BatchSamplingArgs) -> ForwardOutput:
         """P/engine/engine.py:191-206."""

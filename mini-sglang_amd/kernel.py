@@ -72,7 +72,92 @@ class RcclCommunicator:
             self._handle = ctypes.c_void_p()
 
 
-PyNCCLCommunicator = RcclCommunicator
+class P2PCommunicator:
+    """Peer-to-peer collectives over mapped buffers (csrc/comm_p2p.hip): the symmetric-buffer path of the reference's
+    NCCLWrapper (C/src/pynccl.cu:81-90, 105-123) for messages <= max_bytes.  Same surface as PyNCCLCommunicator.
+    Needs only a CPU group for the one-time exchange of IPC handles, so -- unlike RCCL -- two ranks may also share
+    one device (how the N > 1 path is exercised on a 1-GPU box)."""
+
+    def __init__(self, rank: int, world_size: int, cpu_group, max_bytes: int, *, one_shot_max_bytes: int = 256 << 10,
+                 blocks: int = 32) -> None:
+        import torch.distributed as dist
+
+        self._lib = _lib.lib()
+        self._handle = ctypes.c_void_p()
+        self.rank, self.world_size, self.max_bytes = rank, world_size, int(max_bytes)
+        _lib.check(self._lib.msgl_p2p_create(ctypes.byref(self._handle), rank, world_size, self.max_bytes), "p2p_create")
+        mine = ctypes.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+        _lib.check(self._lib.msgl_p2p_ipc_handle(self._handle, mine), "p2p_ipc_handle")
+        handles = [None] * world_size
+        dist.all_gather_object(handles, mine.raw, group=cpu_group)
+        _lib.check(self._lib.msgl_p2p_open(self._handle, b"".join(handles)), "p2p_open")
+        _lib.check(self._lib.msgl_p2p_configure(self._handle, one_shot_max_bytes, blocks), "p2p_configure")
+        dist.barrier(group=cpu_group)  # every rank has mapped every buffer before the first collective
+
+    def fits(self, t: torch.Tensor) -> bool:
+        n = t.numel() * t.element_size()
+        return n <= self.max_bytes and n % 16 == 0 and t.data_ptr() % 16 == 0
+
+    def all_reduce(self, input: torch.Tensor, op: Literal["sum"] = "sum") -> None:
+        if op != "sum":
+            raise ValueError(f"unsupported reduce op {op!r}")
+        if not (input.is_cuda and input.is_contiguous()):
+            raise RuntimeError("Tensor must be a contiguous device tensor")
+        _lib.check(self._lib.msgl_p2p_all_reduce_sum(self._handle, input.data_ptr(), input.numel(), ops._dt(input),
+                                                      torch.cuda.current_stream().cuda_stream), "p2p_all_reduce")
+
+    def all_gather(self, output: torch.Tensor, input: torch.Tensor) -> None:
+        if not (input.is_cuda and input.is_contiguous() and output.is_cuda and output.is_contiguous()):
+            raise RuntimeError("Tensor must be a contiguous device tensor")
+        if output.shape[0] != input.shape[0] * self.world_size:
+            raise RuntimeError("Destination tensor has incorrect size")
+        _lib.check(self._lib.msgl_p2p_all_gather(self._handle, output.data_ptr(), input.data_ptr(), input.numel(),
+                                                  ops._dt(input), torch.cuda.current_stream().cuda_stream),
+                   "p2p_all_gather")
+
+    def error(self) -> int:
+        """0, or 1 + the barrier phase that timed out (sticky; synchronises the device)."""
+        return int(self._lib.msgl_p2p_error(self._handle))
+
+    def get_buffer(self) -> int:
+        return int(self._lib.msgl_p2p_get_buffer(self._handle) or 0)
+
+    def destroy(self) -> None:
+        if self._handle:
+            self._lib.msgl_p2p_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+
+class HybridCommunicator:
+    """What `init_pynccl` returns: messages that fit the mapped buffers go peer to peer (the reference's symmetric
+    window path), the rest through RCCL (its direct path, C/src/pynccl.cu:125-132)."""
+
+    def __init__(self, p2p: Optional[P2PCommunicator], rccl: Optional[RcclCommunicator]) -> None:
+        assert p2p is not None or rccl is not None
+        self.p2p, self.rccl = p2p, rccl
+        self.rank = (p2p or rccl).rank
+        self.world_size = (p2p or rccl).world_size
+
+    def all_reduce(self, input: torch.Tensor, op: Literal["sum"] = "sum") -> None:
+        if self.p2p is not None and (self.rccl is None or self.p2p.fits(input)):
+            return self.p2p.all_reduce(input, op)
+        return self.rccl.all_reduce(input, op)
+
+    def all_gather(self, output: torch.Tensor, input: torch.Tensor) -> None:
+        if self.p2p is not None and (self.rccl is None or self.p2p.fits(input)):
+            return self.p2p.all_gather(output, input)
+        return self.rccl.all_gather(output, input)
+
+    def get_buffer(self) -> int:
+        return (self.p2p or self.rccl).get_buffer()
+
+    def destroy(self) -> None:
+        for c in (self.p2p, self.rccl):
+            if c is not None:
+                c.destroy()
+
+
+PyNCCLCommunicator = HybridCommunicator
 
 
 def create_unique_id() -> bytes:
@@ -81,15 +166,27 @@ def create_unique_id() -> bytes:
     return buf.raw
 
 
-def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int = 0) -> RcclCommunicator:
-    """P/kernel/pynccl.py:47-78: rank 0 creates the unique id, broadcast over the CPU (gloo) group."""
+def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int = 0,
+                backend: str = "hybrid") -> HybridCommunicator:
+    """P/kernel/pynccl.py:47-78.  backend: "hybrid" (peer-to-peer buffers of max_size_bytes + RCCL for larger
+    messages), "rccl" (library only), "p2p" (mapped buffers only: every message must fit; the only choice when two
+    ranks share a device).  RCCL bootstrap as in the reference: rank 0 creates the unique id, broadcast over the CPU
+    (gloo) group."""
     import torch.distributed as dist
 
-    id_list = [create_unique_id() if tp_rank == 0 else None]
-    dist.broadcast_object_list(id_list, src=0, group=tp_cpu_group)
-    uid = id_list[0]
-    assert uid is not None, f"Failed to get RCCL unique ID on {tp_rank = }"
-    return RcclCommunicator(tp_rank, tp_size, max_size_bytes, uid)
+    if backend not in ("hybrid", "rccl", "p2p"):
+        raise ValueError(backend)
+    rccl = p2p = None
+    if backend != "p2p":
+        id_list = [create_unique_id() if tp_rank == 0 else None]
+        dist.broadcast_object_list(id_list, src=0, group=tp_cpu_group)
+        uid = id_list[0]
+        assert uid is not None, f"Failed to get RCCL unique ID on {tp_rank = }"
+        rccl = RcclCommunicator(tp_rank, tp_size, 0, uid)
+    if backend != "rccl" and max_size_bytes > 0 and tp_size <= 8:
+        p2p = P2PCommunicator(tp_rank, tp_size, tp_cpu_group, max_size_bytes)
+    return HybridCommunicator(p2p, rccl)
 
 
-__all__ = ["indexing", "fast_compare_key", "store_cache", "init_pynccl", "PyNCCLCommunicator", "RcclCommunicator"]
+__all__ = ["indexing", "fast_compare_key", "store_cache", "init_pynccl", "PyNCCLCommunicator", "RcclCommunicator",
+           "P2PCommunicator", "HybridCommunicator"]

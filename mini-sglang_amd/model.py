@@ -86,14 +86,22 @@ def lm_head_unshard(gathered: torch.Tensor, tp_size: int, rows: int, vocab_size:
 
 
 class Communicator:
-    """all_reduce / all_gather seam (P/distributed/impl.py:63-70); identity at tp = 1."""
+    """all_reduce / all_gather seam (P/distributed/impl.py:63-70); identity at tp = 1.
 
-    def __init__(self, impl: Any = None, tp_size: int = 1) -> None:
-        self.impl, self.tp_size = impl, tp_size
+    `side` is a second, independent communicator (own buffers / own RCCL communicator) for collectives issued on the
+    side stream: two collectives of one communicator must never be in flight at once."""
+
+    def __init__(self, impl: Any = None, tp_size: int = 1, side: Any = None) -> None:
+        self.impl, self.tp_size, self.side = impl, tp_size, side
 
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         if self.tp_size > 1:
             self.impl.all_reduce(x, "sum")
+        return x
+
+    def all_reduce_side(self, x: torch.Tensor) -> torch.Tensor:
+        if self.tp_size > 1:
+            (self.side or self.impl).all_reduce(x, "sum")
         return x
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
@@ -107,11 +115,17 @@ class Communicator:
 class DenseDecoder:
     def __init__(self, cfg: ModelConfig, *, dtype: torch.dtype, device: torch.device, tp_rank: int = 0,
                  tp_size: int = 1, seed: int = 42, comm: Optional[Communicator] = None, fused: bool = True,
-                 init_std: float = 0.02) -> None:
+                 init_std: float = 0.02, comm_split_tokens: int = 0, comm_overlap: bool = True) -> None:
         self.cfg, self.dtype, self.device = cfg, dtype, device
         self.tp_rank, self.tp_size = tp_rank, tp_size
         self.fused = fused
         self.comm = comm or Communicator(None, tp_size)
+        # row-parallel projections of >= comm_split_tokens tokens run as two token halves so that the all-reduce of
+        # the first half (side stream, second communicator) overlaps the GEMM of the second (0 = never).  Meant for
+        # prefill chunks: a decode batch would stream the weights twice for nothing (its GEMMs are weight-bound).
+        self.comm_split_tokens = comm_split_tokens if tp_size > 1 else 0
+        self.comm_overlap = comm_overlap
+        self.side_stream = torch.cuda.Stream(device=device) if (self.comm_split_tokens and comm_overlap) else None
         D = cfg.head_dim
         self.hq = div_even(cfg.num_qo_heads, tp_size)
         self.hkv = div_even(cfg.num_kv_heads, tp_size, allow_replicate=True)
@@ -209,6 +223,36 @@ class DenseDecoder:
 
         return tune_projection_gemms(self.projection_groups(), batch_sizes, mode, self.dtype, self.device, log=log)
 
+    # ------------------------------------------------------------------ row-parallel projection + all-reduce
+    def row_parallel(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """all_reduce(x @ w^T) (P/layers/linear.py:102-106, 123-127).  north_star: "RCCL all-reduce over xGMI overlapped
+        on a side HIP stream": with >= comm_split_tokens tokens the projection runs per token half; the first half's
+        collective goes to the side stream (its own communicator) while the compute stream runs the second half's
+        GEMM, the second half's collective follows on the compute stream, which then waits for the side stream.
+        comm_overlap=False issues the very same kernels on one stream (the serial path the overlap must equal)."""
+        T = x.shape[0]
+        if self.tp_size == 1:
+            return ops.linear(x, w)
+        if not self.comm_split_tokens or T < self.comm_split_tokens:
+            return self.comm.all_reduce(ops.linear(x, w))
+        h = (T // 2 + 7) // 8 * 8
+        y = torch.empty((T, w.shape[0]), dtype=x.dtype, device=x.device)
+        ops.linear(x[:h], w, out=y[:h])
+        if self.comm_overlap:
+            main, side = torch.cuda.current_stream(), self.side_stream
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                self.comm.all_reduce_side(y[:h])
+                done = side.record_event()
+            ops.linear(x[h:], w, out=y[h:])
+            self.comm.all_reduce(y[h:])
+            main.wait_event(done)
+        else:
+            self.comm.all_reduce_side(y[:h])
+            ops.linear(x[h:], w, out=y[h:])
+            self.comm.all_reduce(y[h:])
+        return y
+
     # ------------------------------------------------------------------ forward
     def forward(self, ctx: Any, batch: Any) -> torch.Tensor:
         """P/models/qwen3.py:77-81 -> logits [B, vocab] (model dtype)."""
@@ -239,11 +283,11 @@ class DenseDecoder:
                 fi.apply_rope_with_cos_sin_cache_inplace(positions=batch.positions, query=q, key=k, head_size=D,
                                                          cos_sin_cache=self.cos_sin)
                 o = backend.forward(q.view(-1, self.hq, D), k, v, li, batch)
-            x = self.comm.all_reduce(ops.linear(o.view(-1, self.q_dim), lw.o))
+            x = self.row_parallel(o.view(-1, self.q_dim), lw.o)
             fi.fused_add_rmsnorm(x, residual, lw.post_norm, cfg.rms_norm_eps)
             gate_up = ops.linear(x, lw.gate_up)
             y = fi.silu_and_mul(gate_up)
-            x = self.comm.all_reduce(ops.linear(y, lw.down))
+            x = self.row_parallel(y, lw.down)
         fi.fused_add_rmsnorm(x, residual, self.final_norm, cfg.rms_norm_eps)
         # LM head (P/layers/embedding.py:88-110)
         bs = batch.size

@@ -1,7 +1,10 @@
-"""N > 1 path on CPU: 2 processes over gloo run the tensor-parallel restatement (sharded
-weights, vocab-parallel embedding with masked gather, row-parallel all-reduce, LM-head
-all-gather + unshard) and must reproduce the single-rank forward; plus the all-reduce /
-all-gather known answers of the reference's tests/kernel/test_comm.py:96-149."""
+"""N > 1 host logic on CPU (2 gloo ranks).  The product's tensor-parallel FORWARD needs the GPU and is checked there
+with two real ranks (tests/test_gpu_tp.py: DenseDecoder(tp_size=2) == tp = 1, peer-to-peer collectives).  Here:
+* the product's sharding rules -- DenseDecoder.load_hf_state (q/k/v and gate/up merging, column / row shards, vocab
+  shards), model.vocab_shard, model.lm_head_unshard -- are run on each rank and must equal the oracle's shard of the
+  same full weights, and the LM-head unshard of a gloo all-gather must rebuild the unsharded logits;
+* the oracle's tensor-parallel restatement reproduces its single-rank forward over the same collectives (keeps the
+  oracle honest), with the all-reduce / all-gather known answers of the reference's tests/kernel/test_comm.py:96-149."""
 import os
 import socket
 
@@ -47,8 +50,43 @@ def _worker(rank, world, port, q):
         g = all_gather(torch.full((8,), float(rank), dtype=torch.bfloat16))
         assert torch.equal(g, torch.arange(world, dtype=torch.bfloat16).repeat_interleave(8))
 
-        # ---- sharded forward == unsharded forward (prefill with a cache hit, then a decode step)
+        # ---- the PRODUCT's sharding (DenseDecoder.load_hf_state on this rank) == the oracle's shard of the same weights
+        import sys
+        from pathlib import Path
+
+        sys.path.insert(0, str(Path(__file__).resolve().parent))
+        import refdrive
+        from mini_sglang_amd.model import DenseDecoder, lm_head_unshard, vocab_shard
+
         cfg = PRESETS["tiny"]
+        state = refdrive.seeded_hf_state("tiny", seed=11)
+        dec = DenseDecoder(cfg, dtype=torch.bfloat16, device=torch.device("cpu"), tp_rank=rank, tp_size=world)
+        dec.load_hf_state(state)
+        layers = []
+        for i in range(cfg.num_layers):
+            p = f"model.layers.{i}."
+            layers.append(dict(
+                input_norm=state[p + "input_layernorm.weight"],
+                qkv=torch.cat([state[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0),
+                q_norm=state[p + "self_attn.q_norm.weight"], k_norm=state[p + "self_attn.k_norm.weight"],
+                o=state[p + "self_attn.o_proj.weight"], post_norm=state[p + "post_attention_layernorm.weight"],
+                gate_up=torch.cat([state[p + "mlp.gate_proj.weight"], state[p + "mlp.up_proj.weight"]], 0),
+                down=state[p + "mlp.down_proj.weight"]))
+        full_w = ref_model.CpuWeights(state["model.embed_tokens.weight"], layers, state["model.norm.weight"],
+                                      state["lm_head.weight"], dec.cos_sin)
+        want = ref_model.shard_weights(cfg, full_w, world, rank)
+        for li, lw in enumerate(dec.layers):
+            for name in ("qkv", "o", "gate_up", "down", "input_norm", "post_norm", "q_norm", "k_norm"):
+                assert torch.equal(getattr(lw, name), want.layers[li][name]), (li, name)
+        per, (start, length) = vocab_shard(cfg.vocab_size, world, rank)
+        assert torch.equal(dec.embed[:length], want.embed[:length]) and torch.equal(dec.lm_head[:length], want.lm_head[:length])
+        # LM head: shard logits -> all-gather -> product's unshard == unsharded logits
+        h = torch.randn((5, cfg.hidden_size), generator=torch.Generator().manual_seed(5))
+        mine_logits = h @ dec.lm_head.float().t()
+        rebuilt = lm_head_unshard(all_gather(mine_logits), world, 5, cfg.vocab_size)
+        torch.testing.assert_close(rebuilt, h @ state["lm_head.weight"].float().t(), atol=1e-5, rtol=1e-5)
+
+        # ---- the oracle's sharded forward == its unsharded forward (prefill with a cache hit, then a decode step)
         dt = torch.float32  # exact-ish comparison: fp32 everywhere, only the summation order differs
         full = ref_model.random_weights(cfg, dt, seed=7)
         mine = ref_model.shard_weights(cfg, full, world, rank)

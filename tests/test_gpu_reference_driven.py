@@ -72,26 +72,9 @@ def repo_engine(dev, model: str, state, rec, llm_kwargs):
 
 def replay(eng, rec):
     """Feed the reference's recorded batches to the repo engine; returns per-forward summaries."""
-    from mini_sglang_amd.core import Batch, Req
+    from replay_util import replay_forward
 
-    dev = eng.device
-    out = []
-    for f in rec["forwards"]:
-        rows = torch.tensor(f["rows"], device=dev)
-        table = f["table"].to(dev)
-        eng.page_table[rows, : table.shape[1]] = table
-        reqs = [Req(input_ids=torch.zeros(dl, dtype=torch.int32), table_idx=row, cached_len=cl, output_len=1 << 20,
-                    uid=uid) for row, cl, dl, uid in zip(f["rows"], f["cached_lens"], f["device_lens"], f["uids"])]
-        batch = Batch(reqs=reqs[: f["size"]], phase=f["phase"])
-        batch.padded_reqs = reqs
-        batch.input_ids, batch.positions, batch.out_loc = (f[k].to(dev) for k in ("input_ids", "positions", "out_loc"))
-        eng.attn_backend.prepare_metadata(batch)
-        with eng.ctx.forward_batch(batch):
-            use_graph = eng.graph_runner.can_use_cuda_graph(batch)
-            assert use_graph == f["graph"], "the two engines disagree on graph replay for this batch"
-            logits = eng.graph_runner.replay(batch) if use_graph else eng.model.forward(eng.ctx, batch)
-        out.append(logits_summary(logits[: f["size"]]))
-    return out
+    return [logits_summary(replay_forward(eng, f)) for f in rec["forwards"]]
 
 
 def assert_bit_identical(rec, mine):

@@ -1,0 +1,182 @@
+"""TEST INFRASTRUCTURE: one tensor-parallel rank (a process) of the product code.
+
+    RANK=r WORLD=n PORT=p python tests/tp_worker.py <mode> <out.pt> [device index]
+
+All ranks may share ONE device (the peer-to-peer communicator needs no RCCL, which refuses two ranks per device):
+that is how N > 1 execution of the product is covered on a 1-GPU box.  Modes:
+  collectives   the reference's known answers (tests/kernel/test_comm.py:96-149: ones -> n^rounds, rank-valued ->
+                n(n-1)/2 with a lagging rank 0, half zeros / half ones, all-gather of rank-valued chunks) at one-shot and
+                two-shot sizes, ragged counts, bit-identity across ranks, hipGraph capture + replay
+  tp_model      DenseDecoder(tp_size = n) through Engine + OfflineRunner on the tiny model: logits of every forward
+                (rank 0 also runs the tp = 1 engine on the same full weights for the parent to compare), KV shards,
+                token-split side-stream overlap on vs off
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def collectives(rank: int, world: int, dev: torch.device) -> dict:
+    from mini_sglang_amd.kernel import P2PCommunicator
+
+    res = {"world": world}
+    comm = P2PCommunicator(rank, world, dist.group.WORLD, max_bytes=8 << 20, one_shot_max_bytes=256 << 10, blocks=16)
+    for name, numel in (("one_shot", 4096), ("two_shot", 256 * 5120), ("ragged_two_shot", 8 * 12345 + 8)):
+        # (1) ones -> n^4 after 4 rounds (exact in bf16 up to 8^4 = 4096)
+        x = torch.ones(numel, dtype=torch.bfloat16, device=dev)
+        for _ in range(4):
+            comm.all_reduce(x)
+        torch.cuda.synchronize()
+        assert bool((x == float(world ** 4)).all()), (name, x[:4])
+        # (2) rank-valued, rank 0 arrives late
+        x = torch.full((numel,), float(rank), dtype=torch.bfloat16, device=dev)
+        if rank == 0:
+            time.sleep(0.3)
+        comm.all_reduce(x)
+        torch.cuda.synchronize()
+        assert bool((x == float(world * (world - 1) // 2)).all()), (name, x[:4])
+        # (3) first half zeros, second half ones
+        x = torch.zeros(numel, dtype=torch.bfloat16, device=dev)
+        x[numel // 2:] = 1
+        comm.all_reduce(x)
+        torch.cuda.synchronize()
+        assert bool((x[: numel // 2] == 0).all()) and bool((x[numel // 2:] == world).all()), name
+        # (4) random data: every rank must hold the SAME bits (rank-ordered sum), close to the fp32 sum
+        g = torch.Generator(device=dev).manual_seed(1234)
+        parts = [torch.randn(numel, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(world)]
+        x = parts[rank].clone()
+        comm.all_reduce(x)
+        torch.cuda.synchronize()
+        want = torch.stack([p.float() for p in parts]).sum(0)
+        assert (x.float() - want).abs().max().item() <= 2 ** -7 * want.abs().max().item(), name
+        res[f"sum_{name}"] = x.cpu()
+        # (5) fp16
+        xh = torch.full((numel,), 0.5 + rank, dtype=torch.float16, device=dev)
+        comm.all_reduce(xh)
+        torch.cuda.synchronize()
+        assert bool((xh == 0.5 * world + world * (world - 1) / 2).all()), name
+    # all-gather of rank-valued chunks
+    src = torch.full((64, 1184), float(rank), dtype=torch.bfloat16, device=dev)
+    dst = torch.empty((64 * world, 1184), dtype=torch.bfloat16, device=dev)
+    comm.all_gather(dst, src)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert bool((dst[64 * r: 64 * (r + 1)] == float(r)).all())
+    # hipGraph: a captured all-reduce replays with fresh data (flags are device-side sequence numbers)
+    buf = torch.zeros(256 * 1024, dtype=torch.bfloat16, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        comm.all_reduce(buf)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+            comm.all_reduce(buf)
+        for it in range(3):
+            buf.fill_(float(rank + it))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert bool((buf == float(world * it + world * (world - 1) // 2)).all()), it
+    # timing (same device for all ranks here: a protocol check, not an xGMI number)
+    x = torch.ones(256 * 5120, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        comm.all_reduce(x)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        comm.all_reduce(x)
+    torch.cuda.synchronize()
+    res["two_shot_2p6MB_us"] = (time.perf_counter() - t0) / 20 * 1e6
+    res["error"] = comm.error()
+    dist.barrier()
+    comm.destroy()
+    return res
+
+
+def tp_model(rank: int, world: int, dev: torch.device) -> dict:
+    import refdrive
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.kernel import init_pynccl
+    from mini_sglang_amd.model import PRESETS
+    from mini_sglang_amd.offline import OfflineRunner
+
+    state = refdrive.seeded_hf_state("tiny", seed=7)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (5, 40, 130, 17, 64, 9)]
+    sp = [SamplingParams(temperature=0.0, max_tokens=5, ignore_eos=True) for _ in prompts]
+    max_bytes = 256 * 256 * 2 * 4
+
+    def engine(tp_size, tp_rank, comm, comm_side, split, overlap):
+        cfg = EngineConfig(model=PRESETS["tiny"], dtype=torch.bfloat16, tp_rank=tp_rank, tp_size=tp_size, max_running_req=8,
+                           page_size=4, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512, num_page_override=512,
+                           comm=comm, comm_side=comm_side, comm_split_tokens=split, comm_overlap=overlap,
+                           tp_cpu_group=dist.group.WORLD if tp_size > 1 else None, gemm_tune="off")
+        eng = Engine(cfg, dev)
+        eng.model.load_hf_state(state)
+        eng.kv_cache._kv_buffer.zero_()
+        return eng
+
+    def run(tp_size, tp_rank, comm, comm_side, split, overlap):
+        from replay_util import record_offline_runner
+
+        eng = engine(tp_size, tp_rank, comm, comm_side, split, overlap)
+        runner = OfflineRunner(eng, max_extend_tokens=96, seed=0)
+        forwards = []
+        record_offline_runner(runner, eng, forwards)
+        runner.generate(prompts, sp)
+        ids = [runner.output_ids(s) for s in runner.last_states]
+        kv = eng.kv_cache._kv_buffer.cpu()
+        eng.shutdown()
+        return dict(ids=ids, forwards=forwards, logits=[f["logits"] for f in forwards], kv=kv)
+
+    def replay_tp1(forwards):
+        """The tp = 1 engine, teacher-forced with the batches the tp = 2 run executed."""
+        from replay_util import replay_forward
+
+        eng = engine(1, 0, None, None, 0, True)
+        logits = [replay_forward(eng, f).float().cpu() for f in forwards]
+        kv = eng.kv_cache._kv_buffer.cpu()
+        eng.shutdown()
+        return dict(logits=logits, kv=kv)
+
+    out = {}
+    comm = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=max_bytes, backend="p2p")
+    side = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=max_bytes, backend="p2p")
+    out["tp"] = run(world, rank, comm, side, 0, True)                 # collectives on the compute stream
+    out["tp_split_serial"] = run(world, rank, comm, side, 32, False)  # token halves, one stream
+    out["tp_split_overlap"] = run(world, rank, comm, side, 32, True)  # first half's all-reduce on the side stream
+    out["comm_error"] = (comm.p2p.error(), side.p2p.error())
+    dist.barrier()
+    comm.destroy()
+    side.destroy()
+    if rank == 0:
+        out["tp1"] = replay_tp1(out["tp"]["forwards"])
+    return out
+
+
+def main() -> None:
+    mode, out_path = sys.argv[1], sys.argv[2]
+    dev = torch.device(f"cuda:{sys.argv[3] if len(sys.argv) > 3 else 0}")
+    rank, world, port = int(os.environ["RANK"]), int(os.environ["WORLD"]), int(os.environ["PORT"])
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = {"collectives": collectives, "tp_model": tp_model}[mode](rank, world, dev)
+    torch.save(res, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
