@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -103,6 +104,31 @@ struct Plan {
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;  // per device
 std::map<Key, Plan> g_plans;
+// Untuned (heuristic) plans are created on first use of a shape; prefill M = total extend tokens takes almost any
+// value, so a long-running server would grow the map without bound.  Tuned plans (decode shapes, a few dozen) are
+// kept; untuned ones are dropped oldest-first beyond this many.
+constexpr size_t kMaxUntunedPlans = 256;
+std::deque<Key> g_untuned_order;
+
+void release_plan(Plan& pl) {
+  delete pl.prob;
+  delete pl.box;
+  pl.prob = nullptr;
+  pl.box = nullptr;
+}
+
+void remember_untuned(const Key& key) {
+  g_untuned_order.push_back(key);
+  while (g_untuned_order.size() > kMaxUntunedPlans) {
+    const Key old = g_untuned_order.front();
+    g_untuned_order.pop_front();
+    auto it = g_plans.find(old);
+    if (it != g_plans.end() && !it->second.tuned) {  // a shape tuned later keeps its plan
+      release_plan(it->second);
+      g_plans.erase(it);
+    }
+  }
+}
 
 int get_handle(hipblasLtHandle_t* h, int* dev_out) {
   int dev = 0;
@@ -210,6 +236,8 @@ int msgl_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, i
     if ((rc = make_problem(pl.prob, M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
     if ((rc = heuristic_plan(h, &pl, ws_bytes)) != MSGL_OK) return rc;
     it = g_plans.emplace(key, pl).first;
+    remember_untuned(key);
+    it = g_plans.find(key);  // (the bound never evicts the entry just added: it is the newest)
   }
   return run(h, it->second, out, x, w, workspace, ws_bytes, static_cast<hipStream_t>(stream));
 }

@@ -211,6 +211,7 @@ struct Philox {
 };
 
 constexpr int kBins = 2048;  // 11-bit digits; thread t owns bins 2047-2t and 2046-2t (descending)
+constexpr uint32_t kNoDigit = 0xffffffffu;
 
 // One radix-select level.  Elements taking part: bits >= floor_bits and (bits & mask) == prefix.
 // BY_MASS = false: find the digit where the descending element COUNT reaches `target`;
@@ -229,6 +230,7 @@ __device__ __forceinline__ uint32_t select_level(const float* __restrict__ row, 
     h_cnt[b] = 0u;
     h_mass[b] = 0ull;
   }
+  if (tid == 0) *s_digit = kNoDigit;  // stays if the row holds less than `target` (fewer than k positive entries)
   __syncthreads();
   for (int64_t i = tid; i < vocab; i += kRowThreads) {
     const float p = row[i];
@@ -250,6 +252,10 @@ __device__ __forceinline__ uint32_t select_level(const float* __restrict__ row, 
   if (above_lo < target && target <= above_lo + q_lo) *s_digit = (uint32_t)b_lo;
   __syncthreads();
   const uint32_t digit = *s_digit;
+  if (digit == kNoDigit) {  // uniform: every thread read the same word
+    __syncthreads();
+    return kNoDigit;
+  }
   // mass strictly above the digit, and quantity strictly above (to reduce the target)
   u64 m_above = 0, q_above = 0;
   if ((uint32_t)b_hi > digit) { m_above += h_mass[b_hi]; q_above += q_hi; }
@@ -287,16 +293,20 @@ __global__ __launch_bounds__(kRowThreads) void sample_kernel(int* __restrict__ o
     uint32_t prefix = 0u, mask = 0u;
     const uint32_t d1 = select_level<false>(row, vocab, 0u, mask, prefix, 21, 11, target, above, dm, h_cnt,
                                             h_mass, lds_w, &s_digit);
-    prefix |= d1 << 21; mask |= 0x7ffu << 21;
-    const uint32_t d2 = select_level<false>(row, vocab, 0u, mask, prefix, 10, 11, target, above, dm, h_cnt,
-                                            h_mass, lds_w, &s_digit);
-    prefix |= d2 << 10; mask |= 0x7ffu << 10;
-    const uint32_t d3 = select_level<false>(row, vocab, 0u, mask, prefix, 0, 10, target, above, dm, h_cnt,
-                                            h_mass, lds_w, &s_digit);
-    prefix |= d3;
-    thr_bits = prefix;  // the k-th largest value; ties at it stay in the keep set
-    kept_mass = above + dm;
-    have_mass = true;
+    // fewer than k positive probabilities (a low temperature underflows the tail to 0): top-k keeps all of them,
+    // as flashinfer does -- no threshold, mass computed below if top-p needs it
+    if (d1 != kNoDigit) {
+      prefix |= d1 << 21; mask |= 0x7ffu << 21;
+      const uint32_t d2 = select_level<false>(row, vocab, 0u, mask, prefix, 10, 11, target, above, dm, h_cnt,
+                                              h_mass, lds_w, &s_digit);
+      prefix |= d2 << 10; mask |= 0x7ffu << 10;
+      const uint32_t d3 = select_level<false>(row, vocab, 0u, mask, prefix, 0, 10, target, above, dm, h_cnt,
+                                              h_mass, lds_w, &s_digit);
+      prefix |= d3;
+      thr_bits = prefix;  // the k-th largest value; ties at it stay in the keep set
+      kept_mass = above + dm;
+      have_mass = true;
+    }
   }
   const float pp = top_p ? top_p[r] : 1.0f;
   if (pp < 1.0f) {
@@ -314,16 +324,18 @@ __global__ __launch_bounds__(kRowThreads) void sample_kernel(int* __restrict__ o
       const uint32_t floor_bits = thr_bits;
       const uint32_t d1 = select_level<true>(row, vocab, floor_bits, mask, prefix, 21, 11, target, above, dm,
                                              h_cnt, h_mass, lds_w, &s_digit);
-      prefix |= d1 << 21; mask |= 0x7ffu << 21;
-      const uint32_t d2 = select_level<true>(row, vocab, floor_bits, mask, prefix, 10, 11, target, above, dm,
-                                             h_cnt, h_mass, lds_w, &s_digit);
-      prefix |= d2 << 10; mask |= 0x7ffu << 10;
-      const uint32_t d3 = select_level<true>(row, vocab, floor_bits, mask, prefix, 0, 10, target, above, dm,
-                                             h_cnt, h_mass, lds_w, &s_digit);
-      prefix |= d3;
-      thr_bits = prefix > thr_bits ? prefix : thr_bits;
-      kept_mass = above + dm;
-      have_mass = true;
+      if (d1 != kNoDigit) {  // (target <= kept_mass, so a digit exists; the guard keeps a bad row from indexing out of range)
+        prefix |= d1 << 21; mask |= 0x7ffu << 21;
+        const uint32_t d2 = select_level<true>(row, vocab, floor_bits, mask, prefix, 10, 11, target, above, dm,
+                                               h_cnt, h_mass, lds_w, &s_digit);
+        prefix |= d2 << 10; mask |= 0x7ffu << 10;
+        const uint32_t d3 = select_level<true>(row, vocab, floor_bits, mask, prefix, 0, 10, target, above, dm,
+                                               h_cnt, h_mass, lds_w, &s_digit);
+        prefix |= d3;
+        thr_bits = prefix > thr_bits ? prefix : thr_bits;
+        kept_mass = above + dm;
+        have_mass = true;
+      }
     }
   }
 

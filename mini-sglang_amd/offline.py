@@ -33,32 +33,30 @@ class RequestState:
     output_events: List = field(default_factory=list)
 
 
-class OfflineRunner:
-    def __init__(self, engine: Engine, max_extend_tokens: int = 8192, seed: int = 0) -> None:
-        self.engine = engine
-        self.device = engine.device
-        self.page_size = engine.cfg.page_size
-        self.max_extend_tokens = max_extend_tokens
-        self.page_table = engine.page_table
-        self.token_pool = torch.zeros_like(self.page_table)  # P/scheduler/table.py:9-10
-        rng = np.random.default_rng(seed)
-        # free pages as page-start token slots (P/scheduler/cache.py:17-20), shuffled: a long-running
-        # server's free list is not sorted, and the kernels must not depend on it being so
-        self.free_slots = (rng.permutation(engine.num_pages).astype(np.int32) * self.page_size)
-        self.free_rows = list(range(engine.cfg.max_running_req))[::-1]
-        self.row_pages: Dict[int, List[np.ndarray]] = {}  # host mirror of what each table row owns
+class PageAllocator:
+    """Host side of the reference's page allocation (P/scheduler/cache.py:15-20, 42-53, 106-146): `free_slots` holds
+    page-START token slots, a batch takes the first `needed` of them in request order, every page expands to
+    page_size consecutive token slots, and those land at positions [first_page, last_page) x page_size of each
+    request's table row.  Pure numpy, no device: the caller scatters (rows, positions, slots) into the page table.
+    Pinned against the reference's own CacheManager trace in tests/test_cpu_host_logic.py."""
 
-    # ------------------------------------------------------------------ allocation
-    def _allocate_paged(self, reqs: Sequence[Req]) -> None:
-        """Pages for positions [cached_len, device_len) of every request (cache.py:42-53)."""
+    def __init__(self, num_pages: int, page_size: int, order: Optional[np.ndarray] = None) -> None:
+        self.page_size = page_size
+        pages = np.arange(num_pages, dtype=np.int64) if order is None else np.asarray(order, dtype=np.int64)
+        self.free_slots = (pages * page_size).astype(np.int32)
+        self.row_pages: Dict[int, List[np.ndarray]] = {}  # which pages each table row received (to give back)
+
+    def allocate(self, reqs: Sequence) -> Optional[tuple]:
+        """Pages for positions [cached_len, device_len) of every request -> (rows, positions, token slots) or None."""
         ps = self.page_size
         first = np.array([-(-r.cached_len // ps) for r in reqs], dtype=np.int64)
         last = np.array([-(-r.device_len // ps) for r in reqs], dtype=np.int64)
         need = np.maximum(last - first, 0)
         total = int(need.sum())
         if total == 0:
-            return
-        assert total <= len(self.free_slots), "KV pool exhausted"
+            return None
+        if total > len(self.free_slots):
+            raise RuntimeError("KV pool exhausted")
         pages, self.free_slots = self.free_slots[:total], self.free_slots[total:]
         off = 0
         for r, n in zip(reqs, need.tolist()):
@@ -70,15 +68,43 @@ class OfflineRunner:
         seg = np.repeat(np.cumsum(need * ps) - need * ps, need * ps)
         pos = starts + (np.arange(total * ps, dtype=np.int64) - seg)
         tok = (pages[:, None] + np.arange(ps, dtype=np.int32)[None, :]).reshape(-1)
+        return rows, pos, tok
+
+    def free_row(self, table_idx: int) -> None:
+        """Give a finished request's pages back, appended in the order they were taken (cache.py:115-119)."""
+        owned = self.row_pages.pop(table_idx, [])
+        if owned:
+            self.free_slots = np.concatenate([self.free_slots] + owned)
+
+
+class OfflineRunner:
+    def __init__(self, engine: Engine, max_extend_tokens: int = 8192, seed: Optional[int] = 0) -> None:
+        self.engine = engine
+        self.device = engine.device
+        self.page_size = engine.cfg.page_size
+        self.max_extend_tokens = max_extend_tokens
+        self.page_table = engine.page_table
+        self.token_pool = torch.zeros_like(self.page_table)  # P/scheduler/table.py:9-10
+        # free pages shuffled (seed) unless seed is None (the reference's initial order, cache.py:19): a long-running
+        # server's free list is not sorted, and the kernels must not depend on it being so
+        order = None if seed is None else np.random.default_rng(seed).permutation(engine.num_pages)
+        self.pages = PageAllocator(engine.num_pages, self.page_size, order)
+        self.free_rows = list(range(engine.cfg.max_running_req))  # pop() hands out the highest row first (table.py:6,17)
+
+    # ------------------------------------------------------------------ allocation
+    def _allocate_paged(self, reqs: Sequence[Req]) -> None:
+        """Pages for positions [cached_len, device_len) of every request (cache.py:42-53) -> page table."""
+        got = self.pages.allocate(reqs)
+        if got is None:
+            return
+        rows, pos, tok = got
         rows_t = torch.from_numpy(rows).pin_memory().to(self.device, non_blocking=True)
         pos_t = torch.from_numpy(pos).pin_memory().to(self.device, non_blocking=True)
         tok_t = torch.from_numpy(tok).pin_memory().to(self.device, non_blocking=True)
         self.page_table[rows_t, pos_t] = tok_t
 
     def _free(self, req: Req) -> None:
-        owned = self.row_pages.pop(req.table_idx, [])
-        if owned:
-            self.free_slots = np.concatenate([self.free_slots] + owned)
+        self.pages.free_row(req.table_idx)
         self.free_rows.append(req.table_idx)
 
     # ------------------------------------------------------------------ batches

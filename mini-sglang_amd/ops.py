@@ -368,7 +368,7 @@ def _gemm_args(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor]):
     return out, M, N, K
 
 
-# (M, N, K, ldx, ldw, dtype code) -> (k-slices, row tiles) of the hand-written weight-streaming kernel, for the
+# (device, M, N, K, ldx, ldw, dtype code) -> (k-slices, row tiles) of the hand-written weight-streaming kernel, for the
 # shapes where skinny_tune() measured it faster than the library's best solution
 _SKINNY_PLAN: dict = {}
 SKINNY_MAX_M = 64
@@ -434,7 +434,7 @@ def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> 
     ranked = sorted((time_us(sl, nt, 1), sl, nt) for sl, nt in skinny_candidates(M, N, K))
     best = min((time_us(sl, nt, 3), sl, nt) for _, sl, nt in ranked[:4])  # re-time the best few
     res.update(skinny_us=best[0], slices=best[1], row_tiles=best[2])
-    key = (M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
     if best[0] < PLAN_MARGIN * library_us:
         _SKINNY_PLAN[key] = (best[1], best[2])
         res["used"] = True
@@ -444,7 +444,7 @@ def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> 
 
 
 # ---- mid-size decode batches: LDS-shared activation tile (csrc/gemm_wstream.hip)
-_WSTREAM_PLAN: dict = {}  # (M, N, K, ldx, ldw, dtype code) -> (row tiles, k splits)
+_WSTREAM_PLAN: dict = {}  # (device, M, N, K, ldx, ldw, dtype code) -> (row tiles, k splits)
 WSTREAM_MAX_M = 256
 
 
@@ -513,7 +513,7 @@ def wstream_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) 
     ranked = sorted((time_us(nt, ks, 1), nt, ks) for nt, ks in cands)
     best = min((time_us(nt, ks, 3), nt, ks) for _, nt, ks in ranked[:4])
     res.update(wstream_us=best[0], row_tiles=best[1], k_splits=best[2], all={f"{nt}x{ks}": round(t, 1) for t, nt, ks in ranked})
-    key = (M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
     if best[0] < PLAN_MARGIN * incumbent_us:
         _WSTREAM_PLAN[key] = (best[1], best[2])
         _SKINNY_PLAN.pop(key, None)
@@ -624,11 +624,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
         if plan:
             return m256_linear(x, w, plan[0], plan[1], plan[2], out)
     if M <= WSTREAM_MAX_M and _WSTREAM_PLAN:
-        plan = _WSTREAM_PLAN.get((M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        plan = _WSTREAM_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
             return wstream_linear(x, w, plan[0], plan[1], out)
     if M <= SKINNY_MAX_M and _SKINNY_PLAN:
-        plan = _SKINNY_PLAN.get((M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        plan = _SKINNY_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
             return skinny_linear(x, w, plan[0], out, plan[1])
     ws = gemm_workspace(x.device)

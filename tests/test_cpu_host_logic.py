@@ -3,6 +3,7 @@ configs[4]), graph batch-size list, the benchmark workload generators (SURVEY.md
 search space of the decode-batch GEMM kernel."""
 import random
 
+import pytest
 import torch
 
 GIB = 1 << 30
@@ -79,3 +80,65 @@ def test_skinny_gemm_search_space_respects_kernel_limits():
     assert not ops.skinny_supported(65, 5120, 5120) and not ops.skinny_supported(8, 40, 128)
     assert not ops.skinny_supported(8, 48, 100) and ops.skinny_supported(64, 48, 64)
     assert ops.linear.__doc__ and not ops._SKINNY_PLAN  # nothing is planned until skinny_tune ran on a GPU
+
+
+def test_page_allocator_reproduces_the_reference_cache_manager_trace(golden_dir):
+    """a12: the product driver's page allocation (offline.PageAllocator, used by OfflineRunner._allocate_paged) against
+    the trace recorded from the REFERENCE's CacheManager + RadixPrefixCache (tests/golden/make_golden.py,
+    gen_cache_allocate: P/scheduler/cache.py:42-53,106-146).  The driver has no prefix cache, so per trace step it is
+    given what the reference had at that point -- the free list left by the previous step and the matched prefix
+    length -- and must hand out exactly the same token slots for the prefill and for each of the three decode steps
+    (pages taken from the head of the free list in order, expanded page-aligned, one new page when a decode step
+    crosses a page boundary), leaving exactly the reference's free list minus what the radix cache gave back."""
+    import types
+
+    import numpy as np
+
+    from mini_sglang_amd.offline import PageAllocator
+
+    gold = torch.load(golden_dir / "cache_allocate.pt")
+    checked = 0
+    for key, ps in (("page1", 1), ("page4", 4)):
+        free_before = torch.arange(gold[key]["num_pages"], dtype=torch.int32) * ps
+        for tr in gold[key]["trace"]:
+            n, cached, row = len(tr["input_ids"]), tr["matched"], tr["table_idx"]
+            alloc = PageAllocator(0, ps)
+            alloc.free_slots = free_before.numpy().copy()
+            table = np.zeros((8, 64), dtype=np.int32)
+            table[row, :cached] = tr["prefill_row"][:cached].numpy()  # the matched prefix comes from the radix tree
+            req = types.SimpleNamespace(table_idx=row, cached_len=cached, device_len=n)
+
+            def step():
+                got = alloc.allocate([req])
+                if got is not None:
+                    rows, pos, tok = got
+                    table[rows, pos] = tok
+
+            try:
+                step()
+                assert np.array_equal(table[row, :n], tr["prefill_row"].numpy()), (key, tr["step"])
+                for _ in range(3):  # complete_one, then the next decode step allocates [cached_len, device_len)
+                    req.cached_len, req.device_len = req.device_len, req.device_len + 1
+                    step()
+            except RuntimeError:  # the reference evicted from its radix cache here; the driver has none
+                free_before = tr["free_slots"]
+                continue
+            assert np.array_equal(table[row, : req.device_len], tr["final_row"].numpy()), (key, tr["step"])
+            # what the driver still holds free is a prefix-preserving part of the reference's next free list: the
+            # reference appends what cache_req frees (cache.py:71-79) behind the untouched remainder
+            rest = alloc.free_slots
+            assert np.array_equal(tr["free_slots"].numpy()[: len(rest)], rest), (key, tr["step"])
+            free_before = tr["free_slots"]
+            checked += 1
+    assert checked >= 8, checked
+
+    # freeing appends in take order (cache.py:115-119), rows are recycled
+    a = PageAllocator(8, 2)
+    r0 = types.SimpleNamespace(table_idx=3, cached_len=0, device_len=5)
+    r1 = types.SimpleNamespace(table_idx=1, cached_len=0, device_len=2)
+    rows, pos, tok = a.allocate([r0, r1])
+    assert tok.tolist() == [0, 1, 2, 3, 4, 5, 6, 7] and rows.tolist() == [3] * 6 + [1] * 2 and pos.tolist() == [0, 1, 2, 3, 4, 5, 0, 1]
+    a.free_row(3)
+    assert a.free_slots.tolist() == [8, 10, 12, 14, 0, 2, 4]
+    with pytest.raises(RuntimeError):
+        a.allocate([types.SimpleNamespace(table_idx=0, cached_len=0, device_len=100)])

@@ -142,7 +142,7 @@ def test_skinny_tune_plans_only_when_faster_and_linear_dispatches(ops, dev):
     ws = [(torch.randn((N, K), generator=g, device=dev) * 0.02).to(torch.bfloat16) for _ in range(3)]
     lib = ops.gemm_tune(x, ws, max_candidates=-8, iters=5)
     rep = ops.skinny_tune(x, ws, lib["best_us"])
-    key = (M, N, K, x.stride(0), ws[0].stride(0), ops._dt(x))
+    key = (x.device.index or 0, M, N, K, x.stride(0), ws[0].stride(0), ops._dt(x))
     assert rep["skinny_us"] is not None and rep["used"] == (rep["skinny_us"] < ops.PLAN_MARGIN * lib["best_us"])
     assert (key in ops._SKINNY_PLAN) == rep["used"]
     _check(ops.linear(x, ws[0]), _ref(x, ws[0]))  # whichever path was planned

@@ -126,13 +126,23 @@ def test_reference_driven_config0_qwen3_0p6b(dev, model_dirs, page_size):
     eng = repo_engine(dev, "qwen3-0.6b", state, rec, kw)
     assert_bit_identical(rec, replay(eng, rec))
     eng.shutdown()
-    # the repo's own driver on the same request: same ids (same batch composition at every step)
+    # the repo's own driver on the same request, free list in the reference's initial order (seed=None): the same
+    # token ids AND the same KV block indices -- table row, page-table contents and out_loc of every forward
+    from replay_util import record_offline_runner
+
     eng = repo_engine(dev, "qwen3-0.6b", state, rec, kw)
-    runner = OfflineRunner(eng, max_extend_tokens=8192, seed=0)
+    runner = OfflineRunner(eng, max_extend_tokens=8192, seed=None)
+    mine_fw = []
+    record_offline_runner(runner, eng, mine_fw)
     runner.generate([prompt], [SamplingParams(temperature=0.0, max_tokens=32, ignore_eos=True)])
     mine = runner.output_ids(runner.last_states[0])
     eng.shutdown()
     assert mine == ids, "greedy ids of the reference-driven run and the repo driver differ"
+    assert len(mine_fw) == len(rec["forwards"])
+    for a, b in zip(mine_fw, rec["forwards"]):
+        assert a["rows"] == b["rows"] and a["device_lens"] == b["device_lens"] and a["cached_lens"] == b["cached_lens"]
+        assert torch.equal(a["out_loc"], b["out_loc"]) and torch.equal(a["positions"], b["positions"])
+        assert torch.equal(a["table"], b["table"]), "page-table rows differ between the two drivers"
 
 
 # ------------------------------------------------------------------------------ (b)+(c) radix / chunked / repeats, tiny dims

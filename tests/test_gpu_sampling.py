@@ -179,3 +179,38 @@ def test_sample_from_logits_matches_probs_path_statistically(ops, dev):
     chi2 = (((a - b) ** 2)[big] / (a + b)[big]).sum().item()
     dof = int(big.sum()) - 1
     assert chi2 < dof + 6 * (2 * dof) ** 0.5 + 10, (chi2, dof)
+
+
+def test_top_k_larger_than_the_number_of_positive_probabilities(ops, dev):
+    """ADVICE r1 (sampling.hip:249): a low-temperature softmax underflows the tail to exactly 0; with top_k above
+    the count of positive entries the count search finds no bin and must behave as 'keep every positive entry'
+    (what flashinfer returns), also when top_p follows.  The sample can only ever be a positive-probability index."""
+    V = 151936
+    g = torch.Generator().manual_seed(5)
+    probs = torch.zeros((6, V), dtype=torch.float32)
+    hot = [int(torch.randint(0, V, (1,), generator=g)) for _ in range(6)]
+    for r, h in enumerate(hot):
+        probs[r, h] = 1.0                      # rows 0-2: one positive entry (T = 1e-6 on a non-greedy row)
+    for r in (3, 4, 5):                        # rows 3-5: three positive entries, k = 50
+        probs[r] = 0
+        probs[r, hot[r]] = 0.7
+        probs[r, (hot[r] + 17) % V] = 0.2
+        probs[r, (hot[r] + 40000) % V] = 0.1
+    pd = probs.to(dev)
+    k = torch.full((6,), 50, dtype=torch.int32, device=dev)
+    p = torch.tensor([0.9, 1e-6, 1.0, 0.5, 0.95, 1.0], dtype=torch.float32, device=dev)
+    allowed = [set(torch.nonzero(probs[r]).flatten().tolist()) for r in range(6)]
+    seen = [set() for _ in range(6)]
+    for it in range(40):
+        for kk, pp in ((k, p), (k, None)):
+            out = ops.sample_top_k_top_p(pd, kk, pp, seed=11, offset=it * 6).cpu().tolist()
+            for r, o in enumerate(out):
+                assert o in allowed[r], (r, o)
+                if pp is None:
+                    seen[r].add(o)
+    for r in range(3):
+        assert seen[r] == {hot[r]}
+    # row 3 with top_p = 0.5 keeps only the 0.7 entry; without top_p all three positives are reachable
+    outs = [ops.sample_top_k_top_p(pd, k, p, seed=3, offset=i * 6).cpu().tolist()[3] for i in range(30)]
+    assert set(outs) == {hot[3]}
+    assert len(seen[5]) >= 2

@@ -24,63 +24,29 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="qwen3-0.6b")
-    ap.add_argument("--num-seqs", type=int, default=256)
-    ap.add_argument("--temperature", type=float, default=0.6)  # the reference bench's value
-    ap.add_argument("--page-size", type=int, default=256)
-    ap.add_argument("--gemm-tune", default="heuristic")
-    ap.add_argument("--out", default="")
-    ap.add_argument("--profile", type=int, default=0, help="cProfile this many decode steps of the same "
-                    "workload instead of the timed run (host-side cost per step)")
-    args = ap.parse_args()
-
+def run(model: str = "qwen3-0.6b", num_seqs: int = 256, temperature: float = 0.6, page_size: int = 256,
+        gemm_tune: str = "heuristic", device=None) -> dict:
+    """One timed generate() of the README workload; returns the result dict (throughput = sum(max_tokens) / wall)."""
     from mini_sglang_amd.core import SamplingParams
     from mini_sglang_amd.engine import Engine, EngineConfig
     from mini_sglang_amd.model import PRESETS
     from mini_sglang_amd.offline import OfflineRunner
 
-    dev = torch.device("cuda:0")
+    dev = device or torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    random.seed(0)
-    n = args.num_seqs
-    prompts = [[random.randint(0, 10000) for _ in range(random.randint(100, 1024))] for _ in range(n)]
-    params = [SamplingParams(temperature=args.temperature, ignore_eos=True, max_tokens=random.randint(100, 1024))
+    rnd = random.Random(0)
+    n = num_seqs
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(100, 1024))] for _ in range(n)]
+    params = [SamplingParams(temperature=temperature, ignore_eos=True, max_tokens=rnd.randint(100, 1024))
               for _ in range(n)]
-    mcfg = PRESETS[args.model]
+    mcfg = PRESETS[model]
     ecfg = EngineConfig(model=mcfg, dtype=torch.bfloat16, max_running_req=n, cuda_graph_max_bs=n,
-                        page_size=args.page_size, max_seq_len_override=4096, memory_ratio=0.9,
-                        gemm_tune=args.gemm_tune)
+                        page_size=page_size, max_seq_len_override=4096, memory_ratio=0.9, gemm_tune=gemm_tune)
     eng = Engine(ecfg, dev)
     runner = OfflineRunner(eng, max_extend_tokens=16384, seed=0)
     runner.warmup_prefill()
     # warm-up generate (bench.py:32: llm.generate(["Benchmark: "], SamplingParams()))
     runner.generate([[1, 2, 3, 4]], [SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=8)])
-    if args.profile:
-        import cProfile
-        import pstats
-        import time
-
-        states = [runner.add_request(p, sp) for p, sp in zip(prompts, params)]
-        for _ in runner.prefill(states):
-            pass
-        running = list(states)
-        for _ in range(10):
-            runner.decode_step(running)
-        torch.cuda.synchronize()
-        pr = cProfile.Profile()
-        t0 = time.perf_counter()
-        pr.enable()
-        for _ in range(args.profile):
-            runner.decode_step(running)
-        pr.disable()
-        t1 = time.perf_counter()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        print(f"host enqueue {1e3 * (t1 - t0) / args.profile:.3f} ms/step, +sync tail {1e3 * (t2 - t1):.1f} ms total", flush=True)
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
-        return
     r = runner.generate(prompts, params)
     out_tokens = sum(p.max_tokens for p in params)
     in_tokens = sum(len(p) for p in prompts)
@@ -93,14 +59,32 @@ def main():
         "prefill_tok_s": in_tokens / (r["prefill_ms"] * 1e-3),
         "ms_per_decode_step": r["decode_ms"] / max(r["decode_steps"], 1),
         "ttft_p50_ms": ttft[int(len(ttft) * 0.5)], "ttft_p99_ms": ttft[int(len(ttft) * 0.99)],
-        "temperature": args.temperature, "page_size": args.page_size, "graph_bs": len(eng.graph_runner.graph_bs_list),
-        "gemm_tune": args.gemm_tune,
+        "temperature": temperature, "page_size": page_size, "graph_bs": len(eng.graph_runner.graph_bs_list),
+        "gemm_tune": gemm_tune,
     }
+    eng.shutdown()
+    del runner, eng
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="qwen3-0.6b")
+    ap.add_argument("--num-seqs", type=int, default=256)
+    ap.add_argument("--temperature", type=float, default=0.6)  # the reference bench's value
+    ap.add_argument("--page-size", type=int, default=256)
+    ap.add_argument("--gemm-tune", default="heuristic")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    res = run(args.model, args.num_seqs, args.temperature, args.page_size, args.gemm_tune)
     print(json.dumps(res), flush=True)
     if args.out:
         Path(args.out).parent.mkdir(parents=True, exist_ok=True)
         Path(args.out).write_text(json.dumps(res, indent=1))
-    eng.shutdown()
 
 
 if __name__ == "__main__":
