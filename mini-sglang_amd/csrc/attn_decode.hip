@@ -204,10 +204,14 @@ __device__ __forceinline__ void pin_tile(Tile& t) {
 // waves per workgroup: with 2 waves/SIMD (3 <= G <= 5) one 8-wave workgroup fills a CU, and for the
 // common hv = 8 it is exactly the 8 kv heads of ONE slot: they walk the same token rows in step, so a
 // 2-KB token row (8 heads x 256 B) is consumed by one CU within a short window (DRAM page / TLB locality).
+#ifndef MSGL_DECODE_WPB
+#define MSGL_DECODE_WPB(G) (((G) >= 3 && (G) <= 5) ? 8 : 4)
+#define MSGL_DECODE_MINW(G) ((G) <= 2 ? 3 : (G) <= 5 ? 2 : 1)
+#endif
 template <int G>
 struct DecodeGeom {
-  static constexpr int kWavesPerBlock = (G >= 3 && G <= 5) ? 8 : 4;
-  static constexpr int kMinWavesPerSimd = G <= 2 ? 3 : G <= 5 ? 2 : 1;
+  static constexpr int kWavesPerBlock = MSGL_DECODE_WPB(G);
+  static constexpr int kMinWavesPerSimd = MSGL_DECODE_MINW(G);
 };
 
 template <typename T, int G, bool kRun>

@@ -204,14 +204,36 @@ def _install_tune_before_capture() -> None:
     GraphRunner._capture_graphs = _capture_graphs
 
 
+# ------------------------------------------------------------------------------ deterministic decode order (opt-in)
+def _install_deterministic_decode_order() -> None:
+    """`DecodeManager.running_reqs` is a `set` of eq=False dataclasses (P/scheduler/decode.py:12,35, P/core.py:28): the
+    decode batch order -- and with it the order `allocate_paged` hands out free pages (P/scheduler/cache.py:42-53) -- is
+    the set's iteration order, i.e. object addresses.  Opt-in: schedule decode batches in uid order, so that two runs
+    of the same request stream produce the same batches and KV block indices."""
+    from minisgl.core import Batch
+    from minisgl.scheduler.decode import DecodeManager
+
+    if getattr(DecodeManager.schedule_next_batch, "_msgl_sorted", False):
+        return
+
+    def schedule_next_batch(self):
+        if not self.runnable:
+            return None
+        return Batch(reqs=sorted(self.running_reqs, key=lambda r: r.uid), phase="decode")
+
+    schedule_next_batch._msgl_sorted = True  # type: ignore[attr-defined]
+    DecodeManager.schedule_next_batch = schedule_next_batch
+
+
 def gemm_report() -> List[dict]:
     """What the last pre-capture search chose (one dict per (batch size, projection))."""
     return list(_STATE["gemm_report"])
 
 
 def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True,
-            gemm_tune: Optional[str] = None) -> None:
-    """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic")."""
+            gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False) -> None:
+    """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic").
+    deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices)."""
     if stub_zmq:
         _stub_zmq()
     _install_flashinfer_shim()
@@ -245,3 +267,5 @@ def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention:
         _install_tune_before_capture()
     if fused_attention:
         _install_fused_attention()
+    if deterministic_decode_order:
+        _install_deterministic_decode_order()

@@ -90,6 +90,15 @@ def test_install_rebinds_every_seam_of_the_reference():
                        ("down", (256, 512), 2, 512)])
         assert got == want, got
         plugin.install(gemm_tune="off")   # idempotent
+        # opt-in: decode batches in uid order (the reference iterates a set of eq=False objects)
+        from minisgl.core import Req, SamplingParams
+        from minisgl.scheduler.decode import DecodeManager
+        dm = DecodeManager(page_size=1)
+        reqs = [Req(input_ids=torch.zeros(3, dtype=torch.int32), table_idx=i, cached_len=0, output_len=4, uid=u,
+                    sampling_params=SamplingParams(), cache_handle=None) for i, u in enumerate([5, 2, 9, 0, 7])]
+        dm.filter_reqs(reqs)
+        plugin.install(gemm_tune="off", deterministic_decode_order=True)
+        assert [r.uid for r in dm.schedule_next_batch().reqs] == [0, 2, 5, 7, 9]
         print("seams ok")
     """)
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(ROOT / "tests"))

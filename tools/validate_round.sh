@@ -1,0 +1,41 @@
+#!/bin/bash
+# End-of-round validation on the GPU box (run through gpurun from the repo root): GPU parity suite, the driver's bench
+# command, rocprofv3 kernel trace of the same command, PMC traffic passes of the dominant kernel.  Every step is
+# bounded by `timeout`; summaries land in gpurun_out/<tag>_* (copy what is to be judged into profiles/).
+TAG=${1:-r02}
+R=$(pwd)
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+( time timeout 900 python -m pytest tests -m gpu -q -x ) > gpurun_out/${TAG}_pytest.log 2>&1
+tail -4 gpurun_out/${TAG}_pytest.log | cut -c1-200
+( time timeout 600 python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+python - <<PY
+import json
+try:
+    d = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+    print("bench:", round(d["value"]), "tok/s", round(d["ms_per_step"], 2), "ms/step; attn", round(d["roofline"]["us_per_launch"], 1), "us frac",
+          round(d["roofline"]["frac"], 3), "traffic", d["roofline"]["traffic"], "; step frac", round(d["step_roofline"]["frac"], 3),
+          "; e2e", {k: round(v.get("throughput_tok_s", 0)) for k, v in d.get("e2e_offline", {}).items()}, "; refdriven", d.get("reference_driven", {}).get("decode_ms_per_step"))
+except Exception as e:
+    print("bench line unreadable:", e)
+PY
+tail -3 gpurun_out/${TAG}_bench.err | cut -c1-300
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_kt -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-prefill-roofline --small-batches > $R/gpurun_out/${TAG}_kt.log 2>&1
+DB=$(find $R/gpurun_out/${TAG}_kt -name "*results.db" | head -1)
+timeout 120 python $R/tools/rocpd_summary.py $DB --top 30 > $R/gpurun_out/${TAG}_bench_kernel_stats.txt 2>&1
+timeout 120 python $R/tools/rocpd_summary.py $DB --top 30 --steps-by sample --last-steps 20 > $R/gpurun_out/${TAG}_bench_timed_steps_kernel_breakdown.txt 2>&1
+head -24 $R/gpurun_out/${TAG}_bench_timed_steps_kernel_breakdown.txt | cut -c1-170
+find $R/gpurun_out/${TAG}_kt -name "*.db" -delete
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $C -d $R/gpurun_out/${TAG}_pmc_$C -- python $R/tools/profile_attn.py --advance 26 > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+  DB=$(find $R/gpurun_out/${TAG}_pmc_$C -name "*results.db" | head -1)
+  timeout 120 python $R/tools/rocpd_summary.py $DB --top 12 > $R/gpurun_out/${TAG}_pmc_$C.txt 2>&1
+  grep -A8 "kernel,counter" $R/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-160
+  find $R/gpurun_out/${TAG}_pmc_$C -name "*.db" -delete
+done
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_attn_kt -- python $R/tools/profile_attn.py --advance 26 > $R/gpurun_out/${TAG}_attn_kt.log 2>&1
+DB=$(find $R/gpurun_out/${TAG}_attn_kt -name "*results.db" | head -1)
+timeout 120 python $R/tools/rocpd_summary.py $DB --top 8 > $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt 2>&1; cut -c1-160 $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt | head -12
+find $R/gpurun_out/${TAG}_attn_kt -name "*.db" -delete
+grep algorithmic $R/gpurun_out/${TAG}_attn_kt.log
