@@ -317,6 +317,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
                    float* best_us, float* default_us, int* best_index, int* best_split_k,
                    int* n_tried, void* stream);
 /* kernel name of the remembered solution into buf; returns its library index (< 0 on error) */
+int msgl_gemm_reset_plans(void);  /* forget all plans: shapes fall back to the library heuristic */
 int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype,
                             char* buf, int buf_len);
 const char* msgl_gemm_last_error(void);

@@ -97,6 +97,7 @@ GEMM_SIGNATURES = {
          C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _p],
     ),
     "msgl_gemm_solution_name": (_i, [_i, _i, _i, _l, _l, _l, _i, C.c_char_p, _i]),
+    "msgl_gemm_reset_plans": (_i, []),
     "msgl_gemm_last_error": (C.c_char_p, []),
 }
 

@@ -422,6 +422,18 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   return MSGL_OK;
 }
 
+// Forget every plan (tuned or not): the next call of a shape takes the library's heuristic again.  Plans are process
+// state; an engine that asks for gemm_tune = "off" must not inherit what an earlier engine searched.
+int msgl_gemm_reset_plans(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  // (Problem objects of tuned plans are shared between the candidates of one search and stay allocated)
+  for (auto& kv : g_plans)
+    if (!kv.second.tuned) release_plan(kv.second);
+  g_plans.clear();
+  g_untuned_order.clear();
+  return MSGL_OK;
+}
+
 int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, char* buf,
                             int buf_len) {
   GEMM_REQUIRE(buf && buf_len > 0, "gemm_solution_name: bad buffer");

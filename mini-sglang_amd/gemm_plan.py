@@ -24,7 +24,10 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
     """mode: "off", "heuristic" (library's top 16 + hand-written kernels), "full" (every library solution at the
     largest batch size, top 16 elsewhere).  Weights of different layers are rotated so candidates are timed from
     HBM, not from the Infinity Cache.  Synchronises: call before graph capture."""
-    if mode == "off" or not batch_sizes:
+    if mode == "off":  # plans are process state: "off" means the library's heuristic, not an earlier engine's search
+        ops.reset_gemm_plans()
+        return []
+    if not batch_sizes:
         return []
     biggest = max(batch_sizes)
     cands = {bs: ({"heuristic": -16, "full": 0}[mode] if bs == biggest else -16) for bs in batch_sizes}

@@ -640,6 +640,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     return out
 
 
+def reset_gemm_plans() -> None:
+    """Drop every per-shape kernel choice made so far in this process (hand-written kernel plans and library
+    solutions): `linear` is the library's heuristic again until the next search."""
+    _SKINNY_PLAN.clear()
+    _WSTREAM_PLAN.clear()
+    _M256_PLAN.clear()
+    _lib.check_gemm(_lib.gemm_lib().msgl_gemm_reset_plans(), "gemm_reset_plans")
+
+
 def gemm_tune(x: torch.Tensor, weights, out: Optional[torch.Tensor] = None, max_candidates: int = 0,
               iters: int = 10, split_k: bool = True) -> dict:
     """Search the library's solutions for x @ w^T over the same-shaped `weights` (rotated so the

@@ -53,9 +53,10 @@ def build(g, specs, hq, hkv, page_size, dtype=torch.bfloat16):
                 hkv=hkv)
 
 
-@pytest.fixture(params=[2, 1], ids=["tr_read", "gen1"])
+@pytest.fixture(params=[3, 2, 1], ids=["paired_heads", "tr_read", "gen1"])
 def impl(request):
-    """Both kernel generations (include/msgl_hip.h: impl 2 = ds_read_b64_tr_b16 kernel, the default; 1 = first one)."""
+    """All kernel generations (include/msgl_hip.h: impl 3 = two q heads per 8-wave workgroup with pipelined scores,
+    2 = ds_read_b64_tr_b16 kernel, 1 = first one)."""
     return request.param
 
 
