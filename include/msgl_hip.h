@@ -192,7 +192,9 @@ int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void*
 /* tile_order (device, [total_tiles], may be NULL = natural order): the order in which q tiles are
  * scheduled -- the host passes tiles sorted by decreasing key count so the launch tail is made of light
  * tiles (results do not depend on it).  impl: 0 = default, 1 = first-generation kernel (V transposed
- * while staging), 2 = ds_read_b64_tr_b16 kernel (double-buffered LDS, XCD-contiguous kv heads). */
+ * while staging), 2 = ds_read_b64_tr_b16 kernel (double-buffered LDS, XCD-contiguous kv heads; softmax scale folded
+ * into the exponent's fma), 3 = the same kernel with the scale applied before the row max (gen-1's arithmetic: the
+ * bit-exact cross-check seam between the two generations). */
 
 /* ------------------------------------------------------------------------
  * Sampling.  Replaces torch.argmax at P/engine/sample.py:73-74 and

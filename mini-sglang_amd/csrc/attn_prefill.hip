@@ -281,7 +281,7 @@ __device__ __forceinline__ uint2 tr_read_b64(const char* lds_ptr) {
 
 constexpr int kTileBytes = kKTile * kD * 2;  // 16 KB: one K (or V) tile image
 
-template <typename T>
+template <typename T, bool kFold = true>
 __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillParams p, int total_tiles) {
   __shared__ __attribute__((aligned(16))) char lds[4 * kTileBytes];  // [buf][K | V]
 
@@ -404,33 +404,61 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
         s[kb] = mfma32<T>(a, qf[ks], s[kb]);
       }
     }
-    // ---- scale, mask, online softmax (lane-local row) ------------------------------------
-    const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
+    // ---- mask, online softmax (lane-local row); kFold: the softmax scale folded into the exponent's fma
     float tmax = kNegBigP;
+    float m_new, alpha, rsum = 0.f;
+    const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
+    if constexpr (!kFold) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = s[kb][r] * p.scale_log2;
-        if (need_mask) {
-          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key > my_qpos) x = -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          float x = s[kb][r] * p.scale_log2;
+          if (need_mask) {
+            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key > my_qpos) x = -INFINITY;
+          }
+          s[kb][r] = x;
+          tmax = fmaxf(tmax, x);
         }
-        s[kb][r] = x;
-        tmax = fmaxf(tmax, x);
       }
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rsum = 0.f;
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      m_new = fmaxf(m_run, tmax);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-        s[kb][r] = e;
-        rsum += e;
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+          s[kb][r] = e;
+          rsum += e;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = s[kb][r];
+          if (need_mask) {
+            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key > my_qpos) x = -INFINITY;
+            s[kb][r] = x;
+          }
+          tmax = fmaxf(tmax, x);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;  // scale > 0: max commutes with it
+      m_new = fmaxf(m_run, tmax);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
+          s[kb][r] = e;
+          rsum += e;
+        }
       }
     }
     rsum += __shfl_xor(rsum, 32, 64);
@@ -487,251 +515,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Third generation: the same tile math as attn_prefill_tr_kernel, restructured around what its counters
-// showed (MFMA pipe 20 % busy: every wave ran QK^T -> softmax -> PV strictly in sequence behind one barrier per
-// tile, two waves per SIMD):
-//   * workgroup = 8 waves = one 128-row q tile of TWO q heads of the same kv head: the K/V tile is staged once
-//     for both (half the global loads, ds_writes and barriers per MFMA; 2 x 16-B pieces per thread);
-//   * three LDS stages (96 KB, one workgroup per CU): tile t+1 is written while tile t is consumed, tile t+2 is
-//     in flight in registers -- still one barrier per tile;
-//   * software pipeline inside a wave: S(t+1) = K(t+1) . Q^T is issued BEFORE the softmax of S(t), so the
-//     matrix pipe works on the next tile's scores while the VALU does exp2 / max / sum of this one; only then
-//     P(t) . V(t).  Two score register sets (s_cur, s_nxt) replace the staging registers saved above.
-// ------------------------------------------------------------------------------------------------
-constexpr int kG3Stages = 3;
-
-template <typename T>
-__global__ __launch_bounds__(512, 1) void attn_prefill_g3_kernel(const PrefillParams p, int total_tiles) {
-  __shared__ __attribute__((aligned(16))) char lds[kG3Stages * 2 * kTileBytes];  // [stage][K | V]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int half = wave >> 2;  // which q head of the pair
-  const int w4 = wave & 3;     // 32-row block of the 128-row q tile
-  const int hi = lane >> 5;
-
-  // ---- block -> (kv head, q tile, head pair): XCD-contiguous virtual index ------------------------
-  const int pairs = (p.group + 1) >> 1;
-  const int hkv = p.hq / p.group;
-  const int n_units = total_tiles * hkv * pairs;
-  const int n_per = (int)(gridDim.x >> 3);
-  const int vidx = (int)(blockIdx.x & 7) * n_per + (int)(blockIdx.x >> 3);
-  if (vidx >= n_units) return;
-  const int per_kv = total_tiles * pairs;
-  const int kvh = vidx / per_kv;
-  const int rem = vidx - kvh * per_kv;
-  const int ti = rem / pairs;
-  const int hg = (rem - ti * pairs) * 2 + half;  // head within the group
-  const bool head_ok = hg < p.group;              // odd group: the last pair has one head
-  const int hq = kvh * p.group + (head_ok ? hg : 0);
-  const int tile = p.tile_order ? p.tile_order[ti] : ti;
-
-  int lo = 0, hi_b = p.batch;
-  while (hi_b - lo > 1) {
-    const int mid = (lo + hi_b) >> 1;
-    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
-  }
-  const int b = lo;
-  const int q_begin = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_begin;
-  const int k_len = p.seq_lens[b];
-  const int q0 = (tile - p.tile_cu[b]) * kQTile;
-  const int row = p.req_rows ? p.req_rows[b] : b;
-  const int* pt = p.page_table + (int64_t)row * p.pt_stride;
-  const int diag = k_len - q_len;
-  const int kend = min(k_len, diag + min(q0 + kQTile, q_len));
-  const int ntiles = (kend + kKTile - 1) / kKTile;
-
-  // ---- Q fragments ------------------------------------------------------------------------------
-  const int my_q = q0 + w4 * 32 + (lane & 31);
-  const bool q_valid = my_q < q_len;
-  const int64_t q_tok = q_begin + (q_valid ? my_q : q_len - 1);
-  U4 qf[8];
-  {
-    const uint16_t* qp = p.q + q_tok * p.q_stride + (int64_t)hq * kD + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = ldg16(qp + ks * 16);
-  }
-  const int my_qpos = diag + my_q;
-  const int wave_min_qpos = diag + q0 + w4 * 32;
-  // tiles this wave computes: those that start at or below its last query position (and only for a real head
-  // whose 32-row block starts inside the sequence)
-  const bool wave_ok = head_ok && (q0 + w4 * 32 < q_len);
-  const int n_w = wave_ok ? min(ntiles, (wave_min_qpos + 31) / kKTile + 1) : 0;
-
-  f32x16 o[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-  float m_run = kNegBigP, l_run = 0.f;
-
-  // ---- staging: thread owns pieces c = tid + 512 i (key = c >> 4 = (tid >> 4) + 32 i, piece = c & 15) --------
-  const int st_key = tid >> 4, st_piece = tid & 15;
-  const int64_t head_off = (int64_t)kvh * p.kv_stride_head + st_piece * 8;
-  int sl[2];
-  U4 kreg[2], vreg[2];
-  auto load_slots = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) sl[i] = pt[min(kt * kKTile + st_key + 32 * i, k_len - 1)];  // never past the sequence
-  };
-  auto issue_loads = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t off = (int64_t)sl[i] * p.kv_stride_tok + head_off;
-      kreg[i] = ldg16(p.k + off);
-      vreg[i] = ldg16(p.v + off);
-    }
-  };
-  auto write_lds = [&](char* buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = st_key + 32 * i;
-      *reinterpret_cast<U4*>(buf + k_off(key, st_piece * 16)) = kreg[i];
-      *reinterpret_cast<U4*>(buf + kTileBytes + v_off(key, st_piece * 16)) = vreg[i];
-    }
-  };
-  int voff[4];
-  {
-    const int j = lane & 15;
-    const int r4 = j >> 2;
-    const int ch = j & 3;
-    const int w = (16 * ((lane >> 4) & 1) + 4 * ch) * 2;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) voff[nb] = kTileBytes + hi * 1024 + r4 * 256 + (((nb ^ r4) & 3) << 6) + w;
-  }
-  auto stage_buf = [&](int kt) -> char* { return lds + (kt % kG3Stages) * (2 * kTileBytes); };
-
-  // S^T = K . Q^T of one tile (raw scores, unscaled)
-  auto scores = [&](const char* buf, f32x16 (&s)[2]) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const int key = kb * 32 + (lane & 31);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const U4 a = *reinterpret_cast<const U4*>(buf + k_off(key, ks * 32 + hi * 16));
-        s[kb] = mfma32<T>(a, qf[ks], s[kb]);
-      }
-    }
-  };
-  // scale, mask, online softmax of tile kt (lane-local row); leaves P in s, rescales o
-  auto softmax = [&](f32x16 (&s)[2], int kt) {
-    const int key0 = kt * kKTile;
-    const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
-    float tmax = kNegBigP;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = s[kb][r] * p.scale_log2;
-        if (need_mask) {
-          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key > my_qpos) x = -INFINITY;
-        }
-        s[kb][r] = x;
-        tmax = fmaxf(tmax, x);
-      }
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rsum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-        s[kb][r] = e;
-        rsum += e;
-      }
-    }
-    rsum += __shfl_xor(rsum, 32, 64);
-    l_run = fmaf(l_run, alpha, rsum);
-    if (!__all(m_new == m_run)) {
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
-    }
-    m_run = m_new;
-  };
-  // O^T += V^T . P^T
-  auto pv = [&](const char* buf, const f32x16 (&s)[2]) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        U4 pf;
-        pf.x = Elem<T>::pack(s[kb][8 * hf + 0], s[kb][8 * hf + 1]);
-        pf.y = Elem<T>::pack(s[kb][8 * hf + 2], s[kb][8 * hf + 3]);
-        pf.z = Elem<T>::pack(s[kb][8 * hf + 4], s[kb][8 * hf + 5]);
-        pf.w = Elem<T>::pack(s[kb][8 * hf + 6], s[kb][8 * hf + 7]);
-        constexpr int kUnitBytes = 4 * 256;
-        const int ub = (kb * 8 + hf * 4) * kUnitBytes;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const uint2 v1 = tr_read_b64(buf + voff[nb] + ub);
-          const uint2 v2 = tr_read_b64(buf + voff[nb] + ub + 2 * kUnitBytes);
-          U4 vf;
-          vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
-          o[nb] = mfma32<T>(vf, pf, o[nb]);
-        }
-      }
-    }
-  };
-
-  f32x16 s_cur[2], s_nxt[2];
-  if (ntiles > 0) {
-    load_slots(0);
-    issue_loads();
-    write_lds(stage_buf(0));
-    if (ntiles > 1) {
-      load_slots(1);
-      issue_loads();
-    }
-    __syncthreads();
-    if (n_w > 0) scores(stage_buf(0), s_cur);
-  }
-  for (int kt = 0; kt < ntiles; ++kt) {
-    // stage (kt+1) % 3 was last read two iterations ago (every wave has passed the barrier of iteration kt-1 since)
-    if (kt + 1 < ntiles) write_lds(stage_buf(kt + 1));
-    if (kt + 2 < ntiles) {
-      load_slots(kt + 2);
-      issue_loads();
-    }
-    __syncthreads();  // tile kt+1 visible
-    if (kt >= n_w) continue;
-    const bool more = kt + 1 < n_w;
-    if (more) scores(stage_buf(kt + 1), s_nxt);  // matrix pipe: next tile's scores ...
-    softmax(s_cur, kt);                           // ... while the VALU finishes this tile's softmax
-    pv(stage_buf(kt), s_cur);
-    if (more) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) s_cur[kb] = s_nxt[kb];
-    }
-  }
-
-  if (q_valid && head_ok) {
-    const float inv = 1.0f / l_run;
-    uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = nb * 32 + 8 * rg + 4 * hi;
-        uint2 w;
-        w.x = Elem<T>::pack(o[nb][4 * rg + 0] * inv, o[nb][4 * rg + 1] * inv);
-        w.y = Elem<T>::pack(o[nb][4 * rg + 2] * inv, o[nb][4 * rg + 3] * inv);
-        *reinterpret_cast<uint2*>(op + d) = w;
-      }
-    }
-  }
-}
-
 }  // namespace msgl
 
 using namespace msgl;
@@ -744,7 +527,7 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
                                  int64_t out_stride_tok, float sm_scale, int dtype, const int32_t* tile_order,
                                  int impl, void* stream) {
   MSGL_REQUIRE(batch >= 0 && total_tiles >= 0, "attn_prefill: negative sizes");
-  MSGL_REQUIRE(impl >= 0 && impl <= 3, "attn_prefill: impl %d (0 default, 1 register-transposed V, 2 tr-read, 3 paired heads)", impl);
+  MSGL_REQUIRE(impl >= 0 && impl <= 3, "attn_prefill: impl %d (0 default, 1 register-transposed V, 2 tr-read, 3 tr-read unfolded scale)", impl);
   if (batch == 0 || total_tiles == 0) return MSGL_OK;
   MSGL_REQUIRE(out && q && k_cache && v_cache && page_table && seq_lens && cu_seqlens_q && tile_cu,
                "attn_prefill: null pointer");
@@ -787,18 +570,14 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
     const dim3 grid((unsigned)total_tiles, (unsigned)num_q_heads), block(256);
     if (dtype == MSGL_BF16) attn_prefill_kernel<BF16><<<grid, block, 0, s>>>(p);
     else attn_prefill_kernel<FP16><<<grid, block, 0, s>>>(p);
-  } else if (impl == 3) {  // third generation: two q heads of a kv head per 8-wave workgroup
-    const int group = num_q_heads / num_kv_heads;
-    const int64_t total = (int64_t)total_tiles * num_kv_heads * ((group + 1) / 2);
-    MSGL_REQUIRE(total < (1ll << 30), "attn_prefill: %lld workgroups", (long long)total);
-    const unsigned blocks = (unsigned)((total + 7) / 8) * 8;
-    if (dtype == MSGL_BF16) attn_prefill_g3_kernel<BF16><<<dim3(blocks), dim3(512), 0, s>>>(p, total_tiles);
-    else attn_prefill_g3_kernel<FP16><<<dim3(blocks), dim3(512), 0, s>>>(p, total_tiles);
   } else {
     const int64_t total = (int64_t)total_tiles * num_q_heads;
     MSGL_REQUIRE(total < (1ll << 30), "attn_prefill: %lld workgroups", (long long)total);
     const unsigned blocks = (unsigned)((total + 7) / 8) * 8;  // 8 XCDs x n_per
-    if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+    if (impl == 3) {
+      if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16, false><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+      else attn_prefill_tr_kernel<FP16, false><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+    } else if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
     else attn_prefill_tr_kernel<FP16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
   }
   MSGL_CHECK_LAUNCH("attn_prefill");

@@ -258,7 +258,7 @@ def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_ca
                  cu_seqlens_q: torch.Tensor, tile_cu: torch.Tensor, batch: int, total_tiles: int,
                  sm_scale: float, tile_order: Optional[torch.Tensor] = None, impl: int = 0) -> None:
     """tile_order: optional int32 [total_tiles] schedule of the q tiles (heaviest first); impl: 0 default,
-    1 first-generation kernel, 2 tr-read kernel (include/msgl_hip.h)."""
+    1 first-generation kernel, 2 tr-read kernel, 3 tr-read kernel with gen-1's softmax arithmetic (include/msgl_hip.h)."""
     _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, cu_seqlens_q, tile_cu)
     if tile_order is not None:
         _need_cuda(tile_order)

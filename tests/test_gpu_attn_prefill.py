@@ -53,10 +53,9 @@ def build(g, specs, hq, hkv, page_size, dtype=torch.bfloat16):
                 hkv=hkv)
 
 
-@pytest.fixture(params=[3, 2, 1], ids=["paired_heads", "tr_read", "gen1"])
+@pytest.fixture(params=[2, 1], ids=["tr_read", "gen1"])
 def impl(request):
-    """All kernel generations (include/msgl_hip.h: impl 3 = two q heads per 8-wave workgroup with pipelined scores,
-    2 = ds_read_b64_tr_b16 kernel, 1 = first one)."""
+    """Both kernel generations (include/msgl_hip.h: impl 2 = ds_read_b64_tr_b16 kernel, the default; 1 = first one)."""
     return request.param
 
 
@@ -131,7 +130,10 @@ def test_prefill_generations_agree(ops, dev):
     """Same fragment ownership and accumulation order in both kernels => identical bits."""
     g = torch.Generator().manual_seed(12)
     c = build(g, [(0, 517), (64, 200), (1000, 1100)], 16, 8, 1)
-    assert torch.equal(run(ops, dev, c, 1), run(ops, dev, c, 2))
+    # impl 3 = the tr-read kernel with the scale applied before the max (gen-1's arithmetic): bit-identical to gen-1;
+    # the default (scale folded into the exponent's fma) differs from it by rounding only
+    assert torch.equal(run(ops, dev, c, 1), run(ops, dev, c, 3))
+    torch.testing.assert_close(run(ops, dev, c, 2).float(), run(ops, dev, c, 3).float(), atol=4e-3, rtol=2 ** -7)
 
 
 def test_prefill_long(ops, dev, impl):
