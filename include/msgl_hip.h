@@ -95,6 +95,11 @@ int msgl_rmsnorm(void* out, const void* x, const void* weight, float eps, int64_
                  int64_t dim, int64_t x_stride0, int64_t x_stride1, int64_t out_stride0,
                  int64_t out_stride1, int dtype, void* stream);
 /* residual <- x + residual (rounded to dtype);  x <- rmsnorm(fp32 sum) * w */
+/* fused_add_rmsnorm whose x is still a split-K projection's partial sums: x_row = round16(sum_s slabs[s]) in slab
+ * order (bit-identical to reducing first), then exactly msgl_fused_add_rmsnorm.  x receives the normalised rows. */
+int msgl_fused_add_rmsnorm_slabs(void* x, void* residual, const void* weight, float eps, int64_t rows,
+                                 int64_t dim, int64_t x_stride, int64_t res_stride, const float* slabs,
+                                 int num_slabs, int64_t slab_stride, int64_t slab_ld, int dtype, void* stream);
 int msgl_fused_add_rmsnorm(void* x, void* residual, const void* weight, float eps, int64_t rows,
                            int64_t dim, int64_t x_stride, int64_t res_stride, int dtype,
                            void* stream);
@@ -256,6 +261,14 @@ int64_t msgl_m256_gemm_workspace_bytes(int M, int N, int full, int tail_split);
 int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
                       int64_t ldo, int dtype, int grid, int full, int tail_split, void* workspace,
                       int64_t workspace_bytes, void* stream);
+/* The k-sliced plan (full == 0, tail_split > 1) without its reduce launch: `workspace` is left holding
+ * tail_split fp32 slabs [M][N] (slab stride M * N floats) for msgl_fused_add_rmsnorm_slabs, the operation that
+ * follows o_proj and down_proj in the reference's decoder layer (P/models/qwen3.py:36-41: the projection output
+ * goes straight into the next layer norm's fused residual add).  The slabs are valid until the next GEMM that
+ * uses the same workspace. */
+int msgl_m256_gemm_slabs_nt(const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                            int dtype, int grid, int tail_split, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 
 /* ------------------------------------------------------------------------
  * Peer-to-peer collectives over xGMI for decode-size messages (libmsgl_hip.so, csrc/comm_p2p.hip).

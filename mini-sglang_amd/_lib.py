@@ -39,6 +39,7 @@ HIP_SIGNATURES = {
     "msgl_fast_compare_key": (_l, [_p, _l, _p, _l, _i]),
     "msgl_rmsnorm": (_i, [_p, _p, _p, _f, _l, _l, _l, _l, _l, _l, _l, _i, _p]),
     "msgl_fused_add_rmsnorm": (_i, [_p, _p, _p, _f, _l, _l, _l, _l, _i, _p]),
+    "msgl_fused_add_rmsnorm_slabs": (_i, [_p, _p, _p, _f, _l, _l, _l, _l, _p, _i, _l, _l, _i, _p]),
     "msgl_rope_neox_inplace": (_i, [_p, _p, _p, _i, _p, _l, _i, _i, _i, _l, _l, _i, _p]),
     "msgl_qk_norm_rope_store": (
         _i,
@@ -76,6 +77,7 @@ HIP_SIGNATURES = {
     "msgl_p2p_release_all": (_i, []),
     "msgl_m256_gemm_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "msgl_m256_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
+    "msgl_m256_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),
 }
 
 COMM_SIGNATURES = {

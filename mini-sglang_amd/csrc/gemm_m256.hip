@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void m256_reduce_kernel(uint16_t* __restrict__
 
 template <typename T>
 static int launch_m256(uint16_t* out, float* part, const uint16_t* x, const uint16_t* w, int M, int N, int K,
-                       int64_t ldx, int64_t ldw, int64_t ldo, int grid, int full, int tail_split, hipStream_t s) {
+                       int64_t ldx, int64_t ldw, int64_t ldo, int grid, int full, int tail_split, hipStream_t s,
+                       bool skip_reduce = false) {
   const int tiles = N / kG2TileN, nsteps = K / kG2StepK;
   const int64_t width = (int64_t)(tiles - full) * kG2TileN;
   static const int abl = getenv("MSGL_M256_ABLATE") ? atoi(getenv("MSGL_M256_ABLATE")) : 0;  // diagnosis only
@@ -291,7 +292,7 @@ static int launch_m256(uint16_t* out, float* part, const uint16_t* x, const uint
     default: MSGL_G2(0); break;
   }
 #undef MSGL_G2
-  if (tail_split > 1 && width > 0) {
+  if (tail_split > 1 && width > 0 && !skip_reduce) {
     const int64_t threads = (int64_t)M * (width / 8);
     m256_reduce_kernel<T><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(
         out, part, M, (int)width, tail_split, ldo, (int64_t)full * kG2TileN);
@@ -311,9 +312,9 @@ extern "C" int64_t msgl_m256_gemm_workspace_bytes(int M, int N, int full, int ta
   return (int64_t)tail_split * M * (int64_t)(N / kG2TileN - full) * kG2TileN * (int64_t)sizeof(float);
 }
 
-extern "C" int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
-                                 int64_t ldo, int dtype, int grid, int full, int tail_split, void* workspace,
-                                 int64_t workspace_bytes, void* stream) {
+static int m256_entry(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                      int64_t ldo, int dtype, int grid, int full, int tail_split, void* workspace,
+                      int64_t workspace_bytes, void* stream, bool skip_reduce) {
   MSGL_REQUIRE(out && x && w, "m256_gemm_nt: null pointer");
   MSGL_REQUIRE(M >= 1 && M <= kG2Rows, "m256_gemm_nt: M = %d outside [1, %d]", M, kG2Rows);
   MSGL_REQUIRE(N >= kG2TileN && N % kG2TileN == 0, "m256_gemm_nt: N = %d must be a multiple of %d", N, kG2TileN);
@@ -336,10 +337,10 @@ extern "C" int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M,
   int rc;
   if (dtype == MSGL_BF16)
     rc = launch_m256<BF16>((uint16_t*)out, (float*)workspace, (const uint16_t*)x, (const uint16_t*)w, M, N, K, ldx, ldw,
-                           ldo, grid, full, tail_split, s);
+                           ldo, grid, full, tail_split, s, skip_reduce);
   else if (dtype == MSGL_FP16)
     rc = launch_m256<FP16>((uint16_t*)out, (float*)workspace, (const uint16_t*)x, (const uint16_t*)w, M, N, K, ldx, ldw,
-                           ldo, grid, full, tail_split, s);
+                           ldo, grid, full, tail_split, s, skip_reduce);
   else {
     set_error("m256_gemm_nt: unsupported dtype code %d", dtype);
     return MSGL_EINVAL;
@@ -347,4 +348,21 @@ extern "C" int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M,
   if (rc != MSGL_OK) return rc;
   MSGL_CHECK_LAUNCH("m256_gemm_nt");
   return MSGL_OK;
+}
+
+extern "C" int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                                 int64_t ldo, int dtype, int grid, int full, int tail_split, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  return m256_entry(out, x, w, M, N, K, ldx, ldw, ldo, dtype, grid, full, tail_split, workspace, workspace_bytes, stream,
+                    false);
+}
+
+// Slabs only: plan must be pure k-slicing (full == 0, tail_split > 1).  `workspace` then holds tail_split fp32 slabs
+// [M][N] (slab stride M * N) for the consumer to add in slab order (msgl_fused_add_rmsnorm_slabs); `out` is not written.
+extern "C" int msgl_m256_gemm_slabs_nt(const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                                       int dtype, int grid, int tail_split, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+  MSGL_REQUIRE(tail_split > 1, "m256_gemm_slabs_nt: needs k-slices (tail_split %d)", tail_split);
+  return m256_entry(workspace, x, w, M, N, K, ldx, ldw, N, dtype, grid, 0, tail_split, workspace, workspace_bytes, stream,
+                    true);
 }

@@ -44,14 +44,19 @@ __device__ __forceinline__ float row_sum(float x, float* lds) {
 // RMSNorm over rows of a logical [n0, n1, dim] tensor.  TPR threads per row, each
 // thread keeps up to KMAX 8-element pieces in registers (dim <= TPR*KMAX*8).
 // FUSED: x += residual (fp32), residual <- rounded sum, x <- norm(fp32 sum) * w.
+// SLABS (with FUSED): x is not read from memory but assembled from `n_slabs` fp32 partial-sum slabs of a split-K
+// projection (slab s at slabs + s * slab_stride, row stride slab_ld), added in slab order and rounded to the
+// 16-bit type first -- exactly what the projection's own reduce kernel would have stored -- so that the reduce
+// launch disappears without changing a bit of the result.
 // ------------------------------------------------------------------------------
-template <typename T, int TPR, int KMAX, bool FUSED>
+template <typename T, int TPR, int KMAX, bool FUSED, bool SLABS = false>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(uint16_t* out, const uint16_t* x,
                                                       uint16_t* residual,
                                                       const uint16_t* __restrict__ weight,
                                                       float eps, int64_t rows, int64_t n1, int dim,
                                                       int64_t xs0, int64_t xs1, int64_t os0,
-                                                      int64_t os1, int64_t rs0) {
+                                                      int64_t os1, int64_t rs0, const float* __restrict__ slabs = nullptr,
+                                                      int n_slabs = 0, int64_t slab_stride = 0, int64_t slab_ld = 0) {
   __shared__ float lds[4];
   constexpr int kRowsPerBlock = 256 / TPR;
   const int tir = threadIdx.x % TPR;  // thread in row
@@ -76,7 +81,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint16_t* out, const uint1
   for (int k = 0; k < KMAX; ++k) {
     const int p = tir + k * TPR;
     if (p < pieces) {
-      unpack8<T>(ldg16(xp + p * 8), v[k]);
+      if constexpr (SLABS) {
+        const float* sp = slabs + r * slab_ld + p * 8;
+        float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+        for (int sl = 1; sl < n_slabs; ++sl) {
+          const float* q = sp + (int64_t)sl * slab_stride;
+          const float4 a2 = *reinterpret_cast<const float4*>(q), b2 = *reinterpret_cast<const float4*>(q + 4);
+          a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+          b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+        }
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unpack8<T>(pack8<T>(f), v[k]);  // the rounded projection output, as the reduce kernel stores it
+      } else {
+        unpack8<T>(ldg16(xp + p * 8), v[k]);
+      }
       if constexpr (FUSED) {
         float rr[8];
         unpack8<T>(ldg16(rp + p * 8), rr);
@@ -241,17 +259,19 @@ static int dispatch_dtype(int dtype, F&& f) {
   return MSGL_EINVAL;
 }
 
-template <typename T, bool FUSED>
+template <typename T, bool FUSED, bool SLABS = false>
 static int launch_rmsnorm(uint16_t* out, const uint16_t* x, uint16_t* res, const uint16_t* w, float eps,
                           int64_t rows, int64_t n1, int64_t dim, int64_t xs0, int64_t xs1, int64_t os0,
-                          int64_t os1, int64_t rs0, hipStream_t s) {
+                          int64_t os1, int64_t rs0, hipStream_t s, const float* slabs = nullptr, int n_slabs = 0,
+                          int64_t slab_stride = 0, int64_t slab_ld = 0) {
   const int pieces = (int)(dim / 8);
 #define MSGL_NORM(TPR, KMAX)                                                                        \
   do {                                                                                              \
     const int64_t rpb = 256 / TPR;                                                                  \
     const int64_t blocks = (rows + rpb - 1) / rpb;                                                  \
-    rmsnorm_kernel<T, TPR, KMAX, FUSED><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(              \
-        out, x, res, w, eps, rows, n1, (int)dim, xs0, xs1, os0, os1, rs0);                          \
+    rmsnorm_kernel<T, TPR, KMAX, FUSED, SLABS><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(       \
+        out, x, res, w, eps, rows, n1, (int)dim, xs0, xs1, os0, os1, rs0, slabs, n_slabs,           \
+        slab_stride, slab_ld);                                                                      \
   } while (0)
   if (pieces <= 8) MSGL_NORM(8, 1);
   else if (pieces <= 16) MSGL_NORM(16, 1);
@@ -344,6 +364,33 @@ extern "C" int msgl_rope_neox_inplace(void* q, void* k, const void* positions, i
   });
   if (rc != MSGL_OK) return rc;
   MSGL_CHECK_LAUNCH("rope_neox_inplace");
+  return MSGL_OK;
+}
+
+extern "C" int msgl_fused_add_rmsnorm_slabs(void* x, void* residual, const void* weight, float eps, int64_t rows,
+                                            int64_t dim, int64_t x_stride, int64_t res_stride, const float* slabs,
+                                            int num_slabs, int64_t slab_stride, int64_t slab_ld, int dtype,
+                                            void* stream) {
+  MSGL_REQUIRE(rows >= 0, "fused_add_rmsnorm_slabs: negative rows");
+  if (rows == 0) return MSGL_OK;
+  MSGL_REQUIRE(x && residual && weight && slabs, "fused_add_rmsnorm_slabs: null pointer");
+  MSGL_REQUIRE(dim > 0 && dim % 8 == 0 && dim <= 16384,
+               "fused_add_rmsnorm_slabs: dim %lld must be a multiple of 8, <= 16384", (long long)dim);
+  MSGL_REQUIRE(num_slabs >= 1 && num_slabs <= 64 && slab_ld >= dim && slab_ld % 4 == 0 && slab_stride % 4 == 0,
+               "fused_add_rmsnorm_slabs: %d slabs, ld %lld, stride %lld", num_slabs, (long long)slab_ld,
+               (long long)slab_stride);
+  MSGL_REQUIRE(x_stride % 8 == 0 && res_stride % 8 == 0, "fused_add_rmsnorm_slabs: strides must be multiples of 8");
+  MSGL_REQUIRE(aligned16(x) && aligned16(residual) && aligned16(weight) && aligned16(slabs),
+               "fused_add_rmsnorm_slabs: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_rmsnorm<T, true, true>((uint16_t*)x, (const uint16_t*)x, (uint16_t*)residual, (const uint16_t*)weight,
+                                         eps, rows, 1, dim, x_stride, 0, x_stride, 0, res_stride, s, slabs, num_slabs,
+                                         slab_stride, slab_ld);
+  });
+  if (rc != MSGL_OK) return rc;
+  MSGL_CHECK_LAUNCH("fused_add_rmsnorm_slabs");
   return MSGL_OK;
 }
 

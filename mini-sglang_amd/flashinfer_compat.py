@@ -24,7 +24,12 @@ def rmsnorm(input: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
 
 def fused_add_rmsnorm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
                       enable_pdl: Optional[bool] = None) -> None:
-    ops.fused_add_rmsnorm(input, residual, weight, eps)
+    slabs = getattr(input, "_msgl_slabs", None)
+    if slabs is not None:  # output of a split-K projection whose reduce was left to this kernel (ops.linear_slabs)
+        del input._msgl_slabs
+        ops.fused_add_rmsnorm_slabs(input, residual, weight, eps, slabs)
+    else:
+        ops.fused_add_rmsnorm(input, residual, weight, eps)
 
 
 # ---- rope (P/layers/rotary.py:45-51) ------------------------------------------------------

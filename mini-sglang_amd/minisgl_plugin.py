@@ -26,7 +26,8 @@ import sys
 import types
 from typing import Any, Dict, List, Optional
 
-_STATE: Dict[str, Any] = {"gemm_tune": "heuristic", "gemm_report": [], "fast_linear": False, "fused_attention": False}
+_STATE: Dict[str, Any] = {"gemm_tune": "heuristic", "gemm_report": [], "fast_linear": False, "fused_attention": False,
+                          "norm_fed_weights": set()}
 
 
 def _stub_zmq() -> None:
@@ -89,6 +90,13 @@ class _FunctionalProxy:
                 and weight.dim() == 2 and x.dim() >= 1 and x.shape[-1] == weight.shape[1] and weight.stride(1) == 1):
             x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
             if x2.stride(1) == 1:
+                if x.dim() == 2 and weight.data_ptr() in _STATE["norm_fed_weights"]:
+                    # o_proj / down_proj of a dense decoder layer at tp = 1: the tensor returned here is the very
+                    # object RMSNormFused.forward passes to fused_add_rmsnorm, which then does the split-K reduce
+                    y, slabs = ops.linear_slabs(x2, weight)
+                    if slabs is not None:
+                        y._msgl_slabs = slabs
+                    return y
                 y = ops.linear(x2, weight)
                 return y if x.dim() == 2 else y.view(*x.shape[:-1], weight.shape[0])
         return self._F.linear(x, weight, bias)
@@ -177,6 +185,38 @@ def _projection_groups(model: Any, require_device: bool = True) -> List[tuple]:
     return groups
 
 
+def _norm_fed_weights(model: Any) -> set:
+    """data_ptr of every projection weight whose output goes, untouched, into the next RMSNormFused's fused residual add:
+    o_proj and down_proj of the dense decoder layers (P/models/qwen3.py:37-41, llama.py:39-43, qwen2.py; the last
+    layer's down_proj feeds the final norm, qwen3.py:63) when no all-reduce sits in between (tp = 1).  Recognised
+    structurally; anything that does not look exactly like that layer is left alone."""
+    from minisgl.layers.base import BaseOP
+    from minisgl.layers.linear import LinearOProj, LinearRowParallel
+    from minisgl.layers.norm import RMSNormFused
+    from minisgl.models.utils import GatedMLP, RopeAttn
+
+    ptrs: set = set()
+
+    def walk(op: Any) -> None:
+        attn, mlp = getattr(op, "self_attn", None), getattr(op, "mlp", None)
+        if (type(attn) is RopeAttn and type(mlp) is GatedMLP
+                and type(getattr(op, "post_attention_layernorm", None)) is RMSNormFused
+                and type(getattr(op, "input_layernorm", None)) is RMSNormFused):
+            o, down = getattr(attn, "o_proj", None), getattr(mlp, "down_proj", None)
+            if (type(o) is LinearOProj and type(down) is LinearRowParallel and o.bias is None and down.bias is None
+                    and o._tp_size == 1 and down._tp_size == 1 and o.weight.is_cuda):
+                ptrs.update((o.weight.data_ptr(), down.weight.data_ptr()))
+            return
+        if isinstance(op, BaseOP):
+            for sub in vars(op).values():
+                for s in (sub if isinstance(sub, (list, tuple)) else (sub,)):
+                    if isinstance(s, BaseOP):
+                        walk(s)
+
+    walk(model)
+    return ptrs
+
+
 def _install_tune_before_capture() -> None:
     from minisgl.engine.graph import GraphRunner
 
@@ -198,6 +238,8 @@ def _install_tune_before_capture() -> None:
                 _STATE["gemm_report"] = tune_projection_gemms(groups, list(self.graph_bs_list), mode, dtype,
                                                               self.device, log=log)
                 torch.cuda.synchronize(self.device)
+        if _STATE["fast_linear"] and os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1":
+            _STATE["norm_fed_weights"] = _norm_fed_weights(model)
         return reference_capture(self, max_seq_len, vocab_size, model)
 
     _capture_graphs._msgl_tuned = True  # type: ignore[attr-defined]

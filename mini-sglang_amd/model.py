@@ -18,11 +18,16 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import flashinfer_compat as fi
 from . import ops
 from .kvcache import div_even
+
+# MSGL_DISABLE_SLAB_NORM=1: keep the split-K reduce of o_proj / down_proj as its own launch (A/B switch)
+_SLAB_NORM = os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1"
 
 
 @dataclass(frozen=True)
@@ -232,7 +237,13 @@ class DenseDecoder:
         comm_overlap=False issues the very same kernels on one stream (the serial path the overlap must equal)."""
         T = x.shape[0]
         if self.tp_size == 1:
-            return ops.linear(x, w)
+            # the caller's next operation is fused_add_rmsnorm: a k-sliced full-batch plan leaves its reduce to it
+            if not _SLAB_NORM:
+                return ops.linear(x, w)
+            y, slabs = ops.linear_slabs(x, w)
+            if slabs is not None:
+                y._msgl_slabs = slabs
+            return y
         if not self.comm_split_tokens or T < self.comm_split_tokens:
             return self.comm.all_reduce(ops.linear(x, w))
         h = (T // 2 + 7) // 8 * 8

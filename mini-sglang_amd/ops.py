@@ -140,6 +140,45 @@ def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Ten
     )
 
 
+class Slabs:
+    """A split-K projection whose reduce has not run: `count` fp32 slabs [rows][dim] in the GEMM workspace of
+    `device`, consumed by fused_add_rmsnorm_slabs before anything else touches that workspace."""
+
+    __slots__ = ("ptr", "count", "rows", "dim", "device")
+
+    def __init__(self, ptr: int, count: int, rows: int, dim: int, device: int):
+        self.ptr, self.count, self.rows, self.dim, self.device = ptr, count, rows, dim, device
+
+
+# device index -> the Slabs whose reduce is still owed (at most one per workspace).  Every GEMM entry point that may
+# use the workspace checks it: a deferred projection output that reached anything but fused_add_rmsnorm is a bug in
+# the caller's wiring and must not turn into silently wrong numbers.
+_PENDING_SLABS: dict = {}
+
+
+def _no_pending_slabs(device: torch.device) -> None:
+    if _PENDING_SLABS and _PENDING_SLABS.get(device.index or 0) is not None:
+        raise RuntimeError("a split-K projection's partial sums are still waiting for fused_add_rmsnorm_slabs: "
+                           "linear_slabs() output was handed to a different consumer")
+
+
+def fused_add_rmsnorm_slabs(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                            slabs: Slabs) -> None:
+    """fused_add_rmsnorm(x, ...) for an x = linear_slabs(...) output whose k-slice sums are still in `slabs`."""
+    _need_cuda(x, residual, weight)
+    assert x.dim() == 2 and x.shape == residual.shape == (slabs.rows, slabs.dim)
+    assert x.dtype == residual.dtype == weight.dtype and x.stride(1) == 1 and residual.stride(1) == 1
+    if _PENDING_SLABS.get(slabs.device) is not slabs:
+        raise RuntimeError("fused_add_rmsnorm_slabs: these partial sums are no longer the workspace's content")
+    _PENDING_SLABS[slabs.device] = None
+    check(
+        lib().msgl_fused_add_rmsnorm_slabs(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), float(eps), x.shape[0],
+                                           x.shape[1], x.stride(0), residual.stride(0), slabs.ptr, slabs.count,
+                                           slabs.rows * slabs.dim, slabs.dim, _dt(x), _stream()),
+        "fused_add_rmsnorm_slabs",
+    )
+
+
 def rope_neox_inplace(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
                       cos_sin_cache: torch.Tensor) -> None:
     _need_cuda(positions, query, key, cos_sin_cache)
@@ -619,6 +658,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     out, M, N, K = _gemm_args(x, w, out)
     if M == 0:
         return out
+    _no_pending_slabs(x.device)
     if M >= M256_MIN_M and _M256_PLAN:
         plan = _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
@@ -640,12 +680,35 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     return out
 
 
+def linear_slabs(x: torch.Tensor, w: torch.Tensor):
+    """`linear` for a projection whose output feeds fused_add_rmsnorm directly: returns (out, slabs).  When the
+    shape's plan is the k-sliced full-batch kernel, the reduce launch is left to the norm (slabs is a Slabs, `out`
+    is allocated but NOT yet written: pass both to fused_add_rmsnorm_slabs); otherwise (out, None) = linear(x, w)."""
+    if x.shape[0] >= M256_MIN_M and _M256_PLAN:
+        _no_pending_slabs(x.device)
+        out, M, N, K = _gemm_args(x, w, None)
+        plan = _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan and plan[1] == 0 and plan[2] > 1:
+            ws = gemm_workspace(x.device)
+            check(
+                lib().msgl_m256_gemm_slabs_nt(x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), _dt(x),
+                                              plan[0], plan[2], ws.data_ptr(), ws.numel(), _stream()),
+                "m256_gemm_slabs_nt",
+            )
+            slabs = Slabs(ws.data_ptr(), plan[2], M, N, x.device.index or 0)
+            _PENDING_SLABS[slabs.device] = slabs
+            return out, slabs
+        return linear(x, w, out), None
+    return linear(x, w), None
+
+
 def reset_gemm_plans() -> None:
     """Drop every per-shape kernel choice made so far in this process (hand-written kernel plans and library
     solutions): `linear` is the library's heuristic again until the next search."""
     _SKINNY_PLAN.clear()
     _WSTREAM_PLAN.clear()
     _M256_PLAN.clear()
+    _PENDING_SLABS.clear()
     _lib.check_gemm(_lib.gemm_lib().msgl_gemm_reset_plans(), "gemm_reset_plans")
 
 

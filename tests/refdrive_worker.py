@@ -51,6 +51,14 @@ def main() -> None:
 
     from refdrive import write_model_dir
 
+    # forced full-batch GEMM plans [[M, N, K, grid, full, tail_split], ...] (contiguous operands, bf16): lets a
+    # bit-identity scenario exercise the hand-written kernel and the reduce-in-norm hand-off without a timing search
+    if spec.get("m256_plans"):
+        from mini_sglang_amd import ops
+
+        for M, N, K, grid, full, split in spec["m256_plans"]:
+            ops._M256_PLAN[(0, M, N, K, K, K, ops._dt(torch.empty(0, dtype=torch.bfloat16)))] = (grid, full, split)
+
     model_dir = spec.get("model_dir")
     if model_dir is None:
         model_dir = str(write_model_dir(Path(tempfile.mkdtemp(prefix="msgl_model_")) / spec["model"], spec["model"],
@@ -142,7 +150,7 @@ def main() -> None:
                graph_bs=list(engine.graph_runner.graph_bs_list), backend=type(engine.attn_backend).__name__,
                attention_forward_fused=bool(getattr(type(engine.model.model.layers.op_list[0].self_attn.attn).forward,
                                                     "_msgl_fused", False)),
-               gemm_report=plugin.gemm_report(), free_pages_end=int(len(cm.free_slots)),
+               gemm_report=plugin.gemm_report(), norm_fed_weights=len(plugin._STATE["norm_fed_weights"]), free_pages_end=int(len(cm.free_slots)),
                evictable_end=int(cm.prefix_cache.size_info.evictable_size), device=torch.cuda.get_device_name(0))
     try:
         cm.check_integrity()

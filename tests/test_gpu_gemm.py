@@ -261,3 +261,41 @@ def test_m256_gemm_rejects_what_it_cannot_do(ops, dev):
         ops.m256_linear(x, w, 256, 0, 5)      # more k-slices than 64-k steps
     with pytest.raises(RuntimeError):
         ops.m256_linear(torch.zeros((257, 256), dtype=torch.bfloat16, device=dev), w, 256, 2, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,split", [(256, 5120, 5120, 6), (256, 5120, 17408, 13), (130, 1024, 3072, 4), (256, 640, 640, 10)])
+def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, split):
+    """o_proj / down_proj -> fused_add_rmsnorm with the projection's slab reduce done by the norm kernel: x and residual
+    bit-identical to reduce-then-norm, the output tensor is the one linear_slabs returned, and a deferred output that
+    reaches any other GEMM fails loudly instead of reading unreduced memory."""
+    from mini_sglang_amd import flashinfer_compat as fi
+
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(dtype)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(dtype)
+    res0 = torch.randn((M, N), generator=g, device=dev).to(dtype)
+    nw = (1 + 0.1 * torch.randn(N, generator=g, device=dev)).to(dtype)
+    key = (dev.index or 0, M, N, K, x.stride(0), w.stride(0), ops._dt(x))
+    ops._M256_PLAN[key] = (256, 0, split)
+    try:
+        y_ref, r_ref = ops.linear(x, w), res0.clone()
+        assert torch.equal(y_ref, ops.m256_linear(x, w, 256, 0, split))
+        ops.fused_add_rmsnorm(y_ref, r_ref, nw, 1e-6)
+        y, slabs = ops.linear_slabs(x, w)
+        assert slabs is not None and slabs.count == split
+        with pytest.raises(RuntimeError, match="partial sums"):
+            ops.linear(x, w)                    # workspace still owed to the norm
+        y._msgl_slabs = slabs
+        r = res0.clone()
+        fi.fused_add_rmsnorm(y, r, nw, 1e-6)   # the shim the reference's RMSNormFused calls
+        assert not hasattr(y, "_msgl_slabs")
+        assert torch.equal(y, y_ref) and torch.equal(r, r_ref)
+        ops.linear(x, w)                        # consumed: GEMMs are allowed again
+        # a plan with whole tiles has no slabs to hand over: linear_slabs is linear
+        ops._M256_PLAN[key] = (256, N // 128, 1)
+        y2, none = ops.linear_slabs(x, w)
+        assert none is None and torch.equal(y2, ops.m256_linear(x, w, 256, N // 128, 1))
+    finally:
+        ops._M256_PLAN.clear()
+        ops._PENDING_SLABS.clear()

@@ -267,6 +267,48 @@ def test_reference_driven_offline_bench_slice_qwen3_0p6b(dev, model_dirs, page_s
               decode_ms=[f.get("ms_to_next") for f in fw if f["phase"] == "decode"][:8]))
 
 
+# ------------------------------------------------------------------------------ (c) full-batch GEMM + reduce-in-norm through the reference's layers
+def test_reference_driven_split_k_projection_reduced_by_the_next_norm(dev, model_dirs, monkeypatch):
+    """o_proj / down_proj of the reference's decoder layer (P/models/qwen3.py:37-41) through the plugin at a decode
+    batch of 160: `F.linear` runs the k-sliced full-batch kernel WITHOUT its reduce launch and the reference's
+    RMSNormFused -> fused_add_rmsnorm adds the slabs.  The repo engine, replaying the same batches with the same
+    plans but a separate reduce kernel, must produce the same bits."""
+    from mini_sglang_amd import model as model_mod
+    from mini_sglang_amd import ops
+
+    mdir, state = model_dirs("qwen3-0.6b")
+    B = 160
+    rnd = random.Random(5)
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(4, 40))] for _ in range(B)]
+    plans = [[B, 1024, 2048, 256, 0, 8], [B, 1024, 3072, 256, 0, 12]]
+    kw = dict(page_size=16, max_running_req=B, cuda_graph_bs=[B], max_seq_len_override=256,
+              num_page_override=4096, max_extend_tokens=8192, cache_type="radix")
+    rec = refdrive.run_worker(dict(model="qwen3-0.6b", model_dir=mdir, llm_kwargs=kw, m256_plans=plans,
+                                   rounds=[dict(prompts=prompts, sampling=[greedy(6)] * B)]))
+    assert rec["integrity"] == "ok" and rec["norm_fed_weights"] == 2 * 28
+    dec = [f for f in rec["forwards"] if f["phase"] == "decode" and f["size"] == B]
+    assert len(dec) >= 4 and all(f["graph"] for f in dec)
+    code = ops._dt(torch.empty(0, dtype=torch.bfloat16))
+    reset = ops.reset_gemm_plans
+
+    def forced_plans_only():  # Engine(gemm_tune="off") resets the process's plans right before it captures
+        reset()
+        for M, N, K, grid, full, split in plans:
+            ops._M256_PLAN[(dev.index or 0, M, N, K, K, K, code)] = (grid, full, split)
+
+    monkeypatch.setattr(ops, "reset_gemm_plans", forced_plans_only)
+    try:
+        for slab_norm in (False, True):   # reduce as its own launch / the engine's own hand-off to the norm
+            monkeypatch.setattr(model_mod, "_SLAB_NORM", slab_norm)
+            eng = repo_engine(dev, "qwen3-0.6b", state, rec, kw)
+            try:
+                assert_bit_identical(rec, replay(eng, rec))
+            finally:
+                eng.shutdown()
+    finally:
+        reset()
+
+
 # ------------------------------------------------------------------------------ the headline workload through the reference
 @pytest.mark.skipif(os.environ.get("MSGL_SKIP_14B_REFDRIVE") == "1", reason="disabled by MSGL_SKIP_14B_REFDRIVE")
 def test_reference_driven_qwen3_14b_decode_step_is_the_benchmarked_path(dev):
