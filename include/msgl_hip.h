@@ -172,6 +172,11 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
                      int max_bs, int capacity, int num_q_heads, int num_kv_heads, int head_dim,
                      int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
                      int64_t out_stride_tok, float sm_scale, int slot_run, int dtype, void* stream);
+/* Which partial-attention kernel msgl_attn_decode_plan / msgl_attn_decode use from now on (process-wide; plan and
+ * launch must be made under the same choice): 0 = default (matrix-core kernel for slot_run >= 16, streaming kernel
+ * otherwise), 1 = streaming kernel only.  Also settable by MSGL_DECODE_IMPL before the first call.  For A/B timing
+ * and tests; both kernels meet the same tolerance against the oracle. */
+int msgl_attn_decode_select(int impl);
 /* slot_run: the caller's guarantee that every ALIGNED run of slot_run positions of a request maps to
  * consecutive token slots (= the engine's page_size under the reference's page-aligned allocation,
  * P/scheduler/cache.py:42-53,127-146; the property fa.py:92-97 relies on).  1 = no guarantee.

@@ -515,6 +515,246 @@ attn_decode_kernel(const DecodeParams p) {
 }
 
 // ------------------------------------------------------------------------------
+// partial attention, matrix-core formulation (pages of >= 16 tokens).
+//
+// The streaming kernel above spends ~350 VALU operations per 16-token tile and wave (dot2 chains, DPP
+// reduce-scatter, fp32 P.V) and half of its wave cycles waiting to issue them (profiles/r01e_pmc_sq_*).  Here the
+// two products go to the otherwise idle matrix cores and the wave is left with ~30 VALU operations per tile:
+//   S^T[16 tokens x 16 heads] = K[16 x 128] . Q^T[128 x 16]   4 x v_mfma_f32_16x16x32 (heads >= G are zero columns)
+//        A = K straight from HBM: lane (token = l & 15, quarter = l >> 4) loads 16 B at dims 32 kk + 8 quarter;
+//   the result puts ONE head (l & 15) and FOUR tokens (4 (l >> 4) + i) in a lane, which is exactly the B-operand
+//   layout of the second product, so P never moves between lanes:
+//   O^T[128 dims x 16 heads] += V^T[128 x 16 tokens] . P^T[16 x 16]   8 x v_mfma_f32_16x16x16
+//        A = V^T: the V rows land in a wave-private 4-KB LDS image (row-major, XOR-swizzled) and come back
+//        transposed through ds_read_b64_tr_b16; no barrier (one wave owns the image, LDS is in order per wave).
+// Softmax: the tile max over the four lane groups by v_permlane16/32_swap; the O rescale (32 registers) runs only
+// on tiles where some head's running max moved.  P is rounded to the 16-bit type for the second product (as in
+// the prefill kernel and in the reference's tensor-core decode, flashinfer), l is summed from the fp32 values.
+// K/V tiles sit in a ring of kStages register sets: kStages - 1 tiles (8 KB each) in flight per wave while one
+// is consumed.  Work split (plan, slots, pieces), partial layout and merge are those of the streaming kernel.
+// ------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 dbf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 df16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 df16x4;
+typedef __attribute__((ext_vector_type(4))) short ds16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) ds16x4 lds_ds16x4;
+typedef __attribute__((address_space(3))) char dlds_char;
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma_k32(const V4& a, const V4& b, f32x4 c) {
+  if constexpr (std::is_same_v<T, BF16>)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dbf16x8, a), __builtin_bit_cast(dbf16x8, b), c, 0,
+                                                   0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(df16x8, a), __builtin_bit_cast(df16x8, b), c, 0, 0,
+                                                  0);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 mfma_k16(const uint2& a, const uint2& b, f32x4 c) {
+  if constexpr (std::is_same_v<T, BF16>)
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(ds16x4, a), __builtin_bit_cast(ds16x4, b), c, 0, 0,
+                                                     0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(df16x4, a), __builtin_bit_cast(df16x4, b), c, 0, 0, 0);
+}
+
+// max over the four 16-lane groups (every lane ends with it)
+__device__ __forceinline__ float max_over_rows(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t w = __float_as_uint(x);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_over_rows(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t w = __float_as_uint(x);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// V image: [16 tokens][256 B]; 64-B blocks XORed by the token's low two bits, the 32-B half by bit 2: the 32 lanes
+// of one ds_read_b64_tr_b16 pass (16 lanes x 2 groups) then cover 32 distinct 8-B bank pairs
+__device__ __forceinline__ int vimg_off(int tok, int byte_in_row) {
+  return tok * 256 + (byte_in_row ^ ((tok & 3) << 6) ^ (((tok >> 2) & 1) << 5));
+}
+
+// kStages: register sets of the request ring; kMfmaWaves: waves per workgroup (8 = the kv heads of one slot at
+// hv = 8); kMinW: waves per SIMD the register budget is held to
+// kLoadsOnly (diagnosis, variant 92): the same requests and waits with the products left out -- what the request
+// pattern alone costs
+template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false>
+__global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kernel(const DecodeParams p) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * 4096];
+  const int lane = threadIdx.x & 63;
+  const int tok = lane & 15;  // token row of the tile for loads; head column for the products' results
+  const int qd = lane >> 4;   // 8-dim quarter of a 32-dim step for loads; token group of the results
+  const int wv = sgpr((int)(threadIdx.x >> 6));
+  const int gw = sgpr((int)blockIdx.x * kMfmaWaves + wv);
+  const int slot = gw / p.hv;
+  const int h = gw - slot * p.hv;
+  const int n_slots = p.plan[3];
+  if (slot >= n_slots) return;
+  const int G = sgpr(p.hq / p.hv);
+  const int* n_chunks = p.plan + plan_off_n_chunks(p.max_bs);
+  const int* slot_first = p.plan + plan_off_slot_first(p.max_bs);
+  const int4* items = reinterpret_cast<const int4*>(p.plan + plan_off_items(p.max_bs, p.capacity));
+  const int item_begin = sgpr(slot_first[slot]);
+  const int item_end = sgpr(slot_first[slot + 1]);
+  dlds_char* img = (dlds_char*)lds + wv * 4096;
+  int wr_off[4], rd_off[8];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) wr_off[kk] = vimg_off(tok, kk * 64 + qd * 16);
+#pragma unroll
+  for (int db = 0; db < 8; ++db) rd_off[db] = vimg_off(4 * qd + (tok >> 2), db * 32 + (tok & 3) * 8);
+
+  for (int item = item_begin; item < item_end; ++item) {
+    const int4 it = items[item];
+    const int b = sgpr(it.x);
+    const int S = sgpr(p.seq_lens[b]);
+    const int t0 = sgpr(it.y) * 16;
+    const int t1 = min(S, sgpr(it.z) * 16);
+    const int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
+    const CInt* cpt = (const CInt*)(p.page_table + (int64_t)row * p.pt_stride);
+    const int hq0 = h * G;
+    const int kvh = hq0 / p.group;
+
+    V4 qf[4];  // B operand of the first product: column = head (tok), k = dims 32 kk + 8 qd ..
+    {
+      const uint16_t* qp = p.q + (int64_t)b * p.q_stride + (int64_t)(hq0 + tok) * D + qd * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        V4 z = {0u, 0u, 0u, 0u};
+        if (tok < G) z = *reinterpret_cast<const V4*>(qp + kk * 32);
+        qf[kk] = z;
+      }
+    }
+    // byte offset of (token row tok, kv head, quarter) from the tile's first token row; step kk adds 64 B
+    const uint32_t voff = (uint32_t)(((int64_t)tok * p.kv_stride_tok + (int64_t)kvh * p.kv_stride_head + qd * 8) * 2);
+    const uint32_t voff0 = (uint32_t)(((int64_t)kvh * p.kv_stride_head + qd * 8) * 2);
+
+    float m = kNegBig, l = 0.f;
+    f32x4 o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (t1 - t0 + 15) >> 4;
+    // Request tile `ti` of the piece (16 tokens from position t0 + 16 ti, first pool slot `sl`).  Tokens at or past t1
+    // re-read the tile's first token (finite data for the masked lanes).  A tile past the piece's end is requested
+    // through a descriptor of ZERO records: the eight loads still issue and retire in order -- the compiler's vmcnt
+    // bookkeeping stays exact, with no branch around the requests -- but touch no memory and return zeros.
+    auto load_tile = [&](int sl, Tile& t, int ti) {
+      const int64_t tile_bytes = (int64_t)sl * p.kv_stride_tok * 2;
+      const int records = sgpr(ti < ntiles ? -1 : 0);
+      const __amdgpu_buffer_rsrc_t kd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.k) + tile_bytes), (short)0, records, 0x00020000);
+      const __amdgpu_buffer_rsrc_t vd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(p.v) + tile_bytes), (short)0, records, 0x00020000);
+      const int vo = (int)(t0 + ti * 16 + tok < t1 ? voff : voff0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        t.k[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, vo + kk * 64, 0, 0));
+        t.v[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, vo + kk * 64, 0, 0));
+      }
+    };
+    auto compute = [&](const Tile& t, int tb) {
+      if constexpr (kLoadsOnly) {
+        l += __uint_as_float((t.k[0].x ^ t.k[1].y ^ t.k[2].z ^ t.k[3].w ^ t.v[0].x ^ t.v[1].y ^ t.v[2].z ^ t.v[3].w) & 0x3fffffffu);
+        return;
+      }
+      // V rows -> the wave's LDS image (the transposing reads below come after these writes: LDS is in order)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<__attribute__((address_space(3))) V4*>(img + wr_off[kk]) = t.v[kk];
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) s = mfma_k32<T>(t.k[kk], qf[kk], s);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)  // only the piece's last tile can be partial; four selects are cheaper than a second body
+        if (tb + 4 * qd + i >= t1) s[i] = -INFINITY;
+      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      mx = max_over_rows(mx) * p.scale_log2;
+      if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {  // some head's running max moved (wave-uniform branch)
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[db][i] *= alpha;
+        }
+      }
+      float pe[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pe[i] = __builtin_amdgcn_exp2f(fmaf(s[i], p.scale_log2, -m));
+      l += (pe[0] + pe[1]) + (pe[2] + pe[3]);
+      uint2 pf;
+      pf.x = Elem<T>::pack(pe[0], pe[1]);
+      pf.y = Elem<T>::pack(pe[2], pe[3]);
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        const ds16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ds16x4*)(img + rd_off[db]));
+        o[db] = mfma_k16<T>(__builtin_bit_cast(uint2, vt), pf, o[db]);
+      }
+    };
+    // One branch-free request pattern for the whole piece: kStages - 1 tiles in flight, then per tile: request tile
+    // cur + kStages - 1, wait for tile cur (pin_tile: that tile only, the younger requests stay in flight under the
+    // products), consume it.  Pool slots come through the scalar cache one tile ahead of their use.
+    Tile ring[kStages];
+    const int lt = ntiles - 1;
+#pragma unroll
+    for (int st = 0; st < kStages - 1; ++st) {
+      load_tile(cpt[t0 + min(st, lt) * 16], ring[st], st);
+      MSGL_PIN_MEM();  // oldest tile first: the scheduler is otherwise free to request them in any order
+    }
+    int sn = cpt[t0 + min(kStages - 1, lt) * 16];  // slot of the next tile to request
+    for (int tix = 0; tix < ntiles; tix += kStages) {
+#pragma unroll
+      for (int st = 0; st < kStages; ++st) {
+        const int cur = tix + st;
+        const int raw = cpt[t0 + min(cur + kStages, lt) * 16];
+        load_tile(sn, ring[(st + kStages - 1) % kStages], cur + kStages - 1);
+        pin_tile(ring[st]);
+        if (cur < ntiles) compute(ring[st], t0 + cur * 16);
+        MSGL_PIN_MEM();
+        sn = raw;
+        asm volatile("" : "+s"(sn));
+      }
+    }
+
+    l = sum_over_rows(l);  // each lane summed its own four tokens per tile
+    if (tok < G) {
+      const int hq = hq0 + tok;
+      if (sgpr(n_chunks[b]) == 1) {
+        const float inv = 1.0f / l;
+        uint16_t* op = p.out + (int64_t)b * p.out_stride + (int64_t)hq * D + 4 * qd;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+          uint2 u;
+          u.x = Elem<T>::pack(o[db][0] * inv, o[db][1] * inv);
+          u.y = Elem<T>::pack(o[db][2] * inv, o[db][3] * inv);
+          *reinterpret_cast<uint2*>(op + db * 16) = u;
+        }
+      } else {
+        float* po = p.part_o + ((int64_t)item * p.hq + hq) * D + 4 * qd;
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+          *reinterpret_cast<float4*>(po + db * 16) = make_float4(o[db][0], o[db][1], o[db][2], o[db][3]);
+        if (qd == 0) {
+          float* pm = p.part_ml + ((int64_t)item * p.hq + hq) * 2;
+          *reinterpret_cast<float2*>(pm) = make_float2(m, l);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
 // merge split-KV partials: one wave per (request, q head), 2 output dims per lane
 // ------------------------------------------------------------------------------
 template <typename T>
@@ -566,7 +806,10 @@ static int resident_waves_of() {
   return cached;
 }
 
-static int resident_waves(int G) {
+static int decode_impl();
+static int mfma_variant(int G);
+
+static int resident_waves_streaming(int G) {
   switch (G) {
     case 1: return resident_waves_of<BF16, 1>();
     case 2: return resident_waves_of<BF16, 2>();
@@ -577,6 +820,15 @@ static int resident_waves(int G) {
     case 7: return resident_waves_of<BF16, 7>();
     default: return resident_waves_of<BF16, 8>();
   }
+}
+
+// the plan does not know the page size, so it is made for whichever of the two kernels keeps more waves resident
+static int resident_waves(int G) {
+  const int streaming = resident_waves_streaming(G);
+  if (decode_impl() == 1) return streaming;
+  const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+  const int mfma = cus * 4 * (mfma_variant(G) / 10);  // attn_decode_mfma_kernel: that many waves per SIMD
+  return mfma > streaming ? mfma : streaming;
 }
 
 // slots the plan may create: one per resident wave of a (virtual) kv head, bounded by the workspace
@@ -597,8 +849,50 @@ static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hip
   return MSGL_OK;
 }
 
+// MSGL_DECODE_IMPL: 0 / unset = matrix-core kernel where it applies (pages of >= 16 tokens), 1 = streaming kernel only
+static int g_decode_impl = -1;
+static int decode_impl() {
+  if (g_decode_impl < 0) g_decode_impl = getenv("MSGL_DECODE_IMPL") ? atoi(getenv("MSGL_DECODE_IMPL")) : 0;
+  return g_decode_impl;
+}
+// matrix-core kernel variants: code = 10 * (waves per SIMD) + ring stages.  Default: two stages (a deeper ring measured
+// the same or slower: tools/decode_ab.py, profiles/r02d_decode_ab.txt) at the residency the plan is made for -- three
+// waves per SIMD where the streaming kernel also has three (G <= 2), two otherwise.  92 = variant 22 without the
+// products (diagnosis).
+static int mfma_variant(int G) {
+  const int c = decode_impl();
+  if (c >= 10 && c < 92) return c;
+  return G <= 2 && c != 92 ? 32 : 22;
+}
+
+template <typename T, int G>
+static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+  // same number of waves as the plan was made for (decode_target_slots): any grid >= n_slots * hv is correct
+  const int64_t waves = (int64_t)decode_target_slots(G, p.hv, capacity, p.max_bs) * p.hv;
+#define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW)                                                         \
+  attn_decode_mfma_kernel<T, STAGES, WAVES, MINW>                                                     \
+      <<<dim3((unsigned)((waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, s>>>(p)
+  switch (decode_impl() == 92 ? 92 : mfma_variant(G)) {
+    case 22: MSGL_MFMA_LAUNCH(2, 8, 2); break;
+    case 23: MSGL_MFMA_LAUNCH(3, 8, 2); break;
+    case 32: MSGL_MFMA_LAUNCH(2, 4, 3); break;
+    case 33: MSGL_MFMA_LAUNCH(3, 4, 3); break;
+    case 42: MSGL_MFMA_LAUNCH(2, 8, 4); break;
+    case 92:
+      attn_decode_mfma_kernel<T, 2, 8, 2, true><<<dim3((unsigned)((waves + 7) / 8)), dim3(512), 0, s>>>(p);
+      break;
+
+    default: MSGL_MFMA_LAUNCH(4, 8, 2); break;
+  }
+#undef MSGL_MFMA_LAUNCH
+  const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
+  attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
+  return MSGL_OK;
+}
+
 template <typename T, int G>
 static int launch_decode(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
+  if (p.slot_run >= 16 && decode_impl() != 1) return launch_decode_mfma<T, G>(p, batch, capacity, s);
   return p.slot_run >= 16 ? launch_decode_run<T, G, true>(p, batch, capacity, s)
                           : launch_decode_run<T, G, false>(p, batch, capacity, s);
 }
@@ -630,6 +924,14 @@ static int heads_per_unit(int group) {
 }  // namespace msgl
 
 using namespace msgl;
+
+extern "C" int msgl_attn_decode_select(int impl) {
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 33 || impl == 42 || impl == 92,
+               "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
+               "w waves per SIMD and s ring stages)", impl);
+  g_decode_impl = impl;
+  return MSGL_OK;
+}
 
 extern "C" int64_t msgl_attn_decode_plan_words(int max_bs, int capacity) {
   if (max_bs < 1 || capacity < max_bs) return MSGL_EINVAL;

@@ -292,6 +292,11 @@ def attn_decode(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cac
     )
 
 
+def attn_decode_select(impl: int) -> None:
+    """0: default kernel choice, 1: streaming (VALU) kernel only -- msgl_attn_decode_select (A/B timing, tests)."""
+    check(lib().msgl_attn_decode_select(int(impl)), "attn_decode_select")
+
+
 def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                  page_table: torch.Tensor, req_rows: Optional[torch.Tensor], seq_lens: torch.Tensor,
                  cu_seqlens_q: torch.Tensor, tile_cu: torch.Tensor, batch: int, total_tiles: int,

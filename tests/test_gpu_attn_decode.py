@@ -97,17 +97,51 @@ def test_decode_matches_oracle_groups(ops, dev, hq, hkv, page_size):
 @pytest.mark.parametrize("page_size,min_chunk", [(16, 16), (64, 64), (256, 64), (256, 256), (48, 32)])
 def test_decode_slot_run_pages(ops, dev, page_size, min_chunk):
     """Page-aligned allocation (P/scheduler/cache.py:42-53): with slot_run = the largest power of two
-    dividing page_size the kernel reads one table entry per tile; results equal the per-token walk
-    bit for bit (same arithmetic, same order) and match the oracle."""
+    dividing page_size the kernel reads one table entry per tile.  Streaming kernel: results equal the per-token
+    walk bit for bit (same arithmetic, same order).  Default choice (matrix-core kernel for runs >= 16): the same
+    tolerance against the oracle."""
     g = torch.Generator().manual_seed(page_size * 7 + min_chunk)
     lens = [1, 16, 17, 31, 32, 33, 47, 48, 49, 255, 256, 257, 700, 1023, 1024, 1025, 2047, 3000, 5, 64]
     case = make_case(g, len(lens), 40, 8, lens, page_size)
     run = page_size & -page_size
-    out_run, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=run)
-    out_tok, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=1)
-    assert torch.isfinite(out_run.float()).all()
-    assert torch.equal(out_run, out_tok)
-    torch.testing.assert_close(out_run.double(), oracle(case), **TOL)
+    ref = oracle(case)
+    try:
+        ops.attn_decode_select(1)
+        out_run, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=run)
+        out_tok, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=1)
+        assert torch.isfinite(out_run.float()).all()
+        assert torch.equal(out_run, out_tok)
+        torch.testing.assert_close(out_run.double(), ref, **TOL)
+    finally:
+        ops.attn_decode_select(0)
+    out_mc, _ = run_decode(ops, dev, case, min_chunk=min_chunk, slot_run=run)
+    assert torch.isfinite(out_mc.float()).all()
+    torch.testing.assert_close(out_mc.double(), ref, **TOL)
+
+
+@pytest.mark.parametrize("hq,hkv,dtype", [(40, 8, torch.bfloat16), (64, 8, torch.bfloat16), (16, 8, torch.float16),
+                                          (8, 8, torch.bfloat16)])
+def test_decode_long_pieces_through_the_request_ring(ops, dev, hq, hkv, dtype):
+    """Enough tokens per slot (~50 tiles) that every wave runs the steady state of the matrix-core kernel's register
+    ring (kStages - 1 tiles in flight), with pieces starting and ending inside requests, ragged last tiles, and
+    requests shorter than the ring.  Both kernels against the oracle; repeatable bit for bit."""
+    g = torch.Generator().manual_seed(hq + hkv)
+    lens = [int(x) for x in torch.randint(2500, 4200, (60,), generator=g)] + [1, 15, 16, 17, 47, 48, 49, 64, 3, 33]
+    case = make_case(g, len(lens), hq, hkv, lens, 256, dtype=dtype)
+    ref = oracle(case)
+    out, _ = run_decode(ops, dev, case, slot_run=256)
+    torch.testing.assert_close(out.double(), ref, **TOL)
+    again, _ = run_decode(ops, dev, case, slot_run=256)
+    assert torch.equal(out, again)
+    try:
+        ops.attn_decode_select(1)
+        out_s, _ = run_decode(ops, dev, case, slot_run=256)
+        torch.testing.assert_close(out_s.double(), ref, **TOL)
+    finally:
+        ops.attn_decode_select(0)
+    err = (out.double() - ref).abs()
+    print(f"\n[decode long pieces hq={hq} hkv={hkv} {dtype}] max abs err {err.max():.2e}, mean {err.mean():.2e}; "
+          f"streaming kernel max {(out_s.double() - ref).abs().max():.2e}")
 
 
 def read_plan(plan, max_bs, capacity, batch):

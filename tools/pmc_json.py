@@ -40,6 +40,15 @@ def pick(d, key):
     raise KeyError(key)
 
 
+def pick_attn(d):
+    """(kernel name, value) of the partial-attention kernel that ran: matrix-core or streaming."""
+    for key in ("attn_decode_mfma_kernel", "attn_decode_kernel"):
+        for k, v in d.items():
+            if key in k:
+                return k, v
+    raise KeyError("attn_decode*_kernel")
+
+
 def main():
     fetch_txt, write_txt, kt_txt, algo, out = sys.argv[1:6]
     note = sys.argv[6] if len(sys.argv) > 6 else ""
@@ -52,15 +61,17 @@ def main():
     fetch_ratio = cf[1] * 1024 / (3 * GIB)
     write_ratio = cw[1] * 1024 / (3 * GIB)
     corr = 1.0 / fetch_ratio
-    fa, fm = pick(f, "attn_decode_kernel")[2], pick(f, "attn_decode_merge")[2]
-    wa, wm = pick(w, "attn_decode_kernel")[2], pick(w, "attn_decode_merge")[2]
+    kname, fa = pick_attn(f)
+    fa, fm = fa[2], pick(f, "attn_decode_merge")[2]
+    wa, wm = pick_attn(w)[1][2], pick(w, "attn_decode_merge")[2]
     hbm = ((fa + fm) * corr + (wa + wm) / write_ratio) * 1024
-    ta, tm = pick(t, "attn_decode_kernel"), pick(t, "attn_decode_merge")
+    ta, tm = pick_attn(t)[1], pick(t, "attn_decode_merge")
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and --kernel-trace --stats "
                   "-- python tools/profile_attn.py, MI355X" + (", " + note if note else ""),
-        "workload": "attn_decode_kernel<BF16,5,kRun> + merge, Qwen3-14B TP1 shape, B=256, bench contexts + 46 "
+        "workload": f"{kname.split('(')[0][:60]} + merge, Qwen3-14B TP1 shape, B=256, bench contexts + 46 "
                     "(= bench.py's roofline launch at default steps), page_size 256",
+        "launch_shape": "qwen3-14b tp1 B256 page256 bench_contexts",
         "algorithmic_bytes_per_launch": algo,
         "fetch_size_kb": {"attn": fa, "merge": fm},
         "write_size_kb": {"attn": wa, "merge": wm},

@@ -39,3 +39,6 @@ DB=$(find $R/gpurun_out/${TAG}_attn_kt -name "*results.db" | head -1)
 timeout 120 python $R/tools/rocpd_summary.py $DB --top 8 > $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt 2>&1; cut -c1-160 $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt | head -12
 find $R/gpurun_out/${TAG}_attn_kt -name "*.db" -delete
 grep algorithmic $R/gpurun_out/${TAG}_attn_kt.log
+ALGO=$(grep algorithmic_bytes_per_launch $R/gpurun_out/${TAG}_attn_kt.log | awk '{print $2}')
+python $R/tools/pmc_json.py $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt \
+  $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt $ALGO $R/gpurun_out/${TAG}_pmc_attn_decode.json "validate_round.sh $TAG" | cut -c1-400
