@@ -174,9 +174,17 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
                      int64_t out_stride_tok, float sm_scale, int slot_run, int dtype, void* stream);
 /* Which partial-attention kernel msgl_attn_decode_plan / msgl_attn_decode use from now on (process-wide; plan and
  * launch must be made under the same choice): 0 = default (matrix-core kernel for slot_run >= 16, streaming kernel
- * otherwise), 1 = streaming kernel only.  Also settable by MSGL_DECODE_IMPL before the first call.  For A/B timing
- * and tests; both kernels meet the same tolerance against the oracle. */
+ * otherwise), 1 = streaming kernel only; for timing and diagnosis also 10 w + s = matrix-core kernel held to w waves
+ * per SIMD with an s-stage request ring (22, 23, 24, 32), 92 = variant 22 with the products left out (what the
+ * request pattern alone costs), 93 = variant 22 leaving clock stamps (msgl_attn_decode_trace).  Also settable by
+ * MSGL_DECODE_IMPL before the first call.  Both kernels meet the same tolerance against the oracle. */
 int msgl_attn_decode_select(int impl);
+/* Diagnosis: under msgl_attn_decode_select(93) every wave leaves 16 uint64 shader-clock stamps at stamps[16 * wave]:
+ * [0] entry, [1] slot known, then per piece i: [2 + 4 i] metadata known, [3 + 4 i] first tile arrived, [4 + 4 i] last
+ * tile consumed, [5 + 4 i] results stored; [14] = stamps taken, [15] = exit.  Clocks are per XCD: only differences
+ * inside one wave mean anything.  `stamps` (device memory, 128 bytes per launched wave) stays registered until
+ * replaced; NULL unregisters.  tools/decode_trace.py. */
+int msgl_attn_decode_trace(void* stamps);
 /* slot_run: the caller's guarantee that every ALIGNED run of slot_run positions of a request maps to
  * consecutive token slots (= the engine's page_size under the reference's page-aligned allocation,
  * P/scheduler/cache.py:42-53,127-146; the property fa.py:92-97 relies on).  1 = no guarantee.

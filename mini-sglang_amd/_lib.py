@@ -48,6 +48,7 @@ HIP_SIGNATURES = {
     "msgl_silu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_gelu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_attn_decode_select": (_i, [_i]),
+    "msgl_attn_decode_trace": (_i, [_p]),
     "msgl_attn_decode_plan_words": (_l, [_i, _i]),
     "msgl_attn_decode_workspace_bytes": (_l, [_i, _i, _i]),
     "msgl_attn_decode_plan": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

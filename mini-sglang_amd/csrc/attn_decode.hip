@@ -186,6 +186,7 @@ struct DecodeParams {
   int max_bs, capacity, hq, hv, group;  // hv = virtual kv heads (hq / G), group = hq / real kv heads
   int slot_run;               // aligned runs of this many positions map to consecutive slots (1: none)
   float scale_log2;
+  unsigned long long* trace;  // diagnosis (msgl_attn_decode_trace): 16 clock stamps per wave, else nullptr
 };
 
 struct Tile {
@@ -587,10 +588,19 @@ __device__ __forceinline__ int vimg_off(int tok, int byte_in_row) {
 // hv = 8); kMinW: waves per SIMD the register budget is held to
 // kLoadsOnly (diagnosis, variant 92): the same requests and waits with the products left out -- what the request
 // pattern alone costs
-template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false>
+template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false, bool kTrace = false>
 __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kernel(const DecodeParams p) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * 4096];
+  unsigned long long stamp[14];  // kTrace (variant 93) only
+  int n_stamp = 0;
+  auto mark = [&]() {
+    if constexpr (kTrace) {
+      if (n_stamp < 14) stamp[n_stamp] = __builtin_readcyclecounter();
+      ++n_stamp;
+    }
+  };
+  mark();  // 0: entry
   const int lane = threadIdx.x & 63;
   const int tok = lane & 15;  // token row of the tile for loads; head column for the products' results
   const int qd = lane >> 4;   // 8-dim quarter of a 32-dim step for loads; token group of the results
@@ -613,6 +623,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
 #pragma unroll
   for (int db = 0; db < 8; ++db) rd_off[db] = vimg_off(4 * qd + (tok >> 2), db * 32 + (tok & 3) * 8);
 
+  mark();  // 1: slot known
   for (int item = item_begin; item < item_end; ++item) {
     const int4 it = items[item];
     const int b = sgpr(it.x);
@@ -620,9 +631,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
     const int t0 = sgpr(it.y) * 16;
     const int t1 = min(S, sgpr(it.z) * 16);
     const int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
+    const bool single = sgpr(n_chunks[b]) == 1;  // read here, with the rest of the metadata, not on the way out
     const CInt* cpt = (const CInt*)(p.page_table + (int64_t)row * p.pt_stride);
     const int hq0 = h * G;
     const int kvh = hq0 / p.group;
+    mark();  // 2 + 4 i: piece i metadata known
 
     V4 qf[4];  // B operand of the first product: column = head (tok), k = dims 32 kk + 8 qd ..
     {
@@ -720,6 +733,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
         const int raw = cpt[t0 + min(cur + kStages, lt) * 16];
         load_tile(sn, ring[(st + kStages - 1) % kStages], cur + kStages - 1);
         pin_tile(ring[st]);
+        if constexpr (kTrace) {
+          if (cur == 0) mark();  // 3 + 4 i: first tile of the piece has arrived
+        }
         if (cur < ntiles) compute(ring[st], t0 + cur * 16);
         MSGL_PIN_MEM();
         sn = raw;
@@ -727,10 +743,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
       }
     }
 
+    mark();  // 4 + 4 i: last tile consumed
     l = sum_over_rows(l);  // each lane summed its own four tokens per tile
     if (tok < G) {
       const int hq = hq0 + tok;
-      if (sgpr(n_chunks[b]) == 1) {
+      if (single) {
         const float inv = 1.0f / l;
         uint16_t* op = p.out + (int64_t)b * p.out_stride + (int64_t)hq * D + 4 * qd;
 #pragma unroll
@@ -750,6 +767,15 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
           *reinterpret_cast<float2*>(pm) = make_float2(m, l);
         }
       }
+    }
+    mark();  // 5 + 4 i: results stored (issued)
+  }
+  if constexpr (kTrace) {
+    if (p.trace && lane == 0) {
+      unsigned long long* tp = p.trace + (int64_t)gw * 16;
+      for (int i = 0; i < 14; ++i) tp[i] = i < n_stamp ? stamp[i] : 0ull;
+      tp[14] = (unsigned long long)n_stamp;
+      tp[15] = __builtin_readcyclecounter();  // exit
     }
   }
 }
@@ -851,6 +877,7 @@ static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hip
 
 // MSGL_DECODE_IMPL: 0 / unset = matrix-core kernel where it applies (pages of >= 16 tokens), 1 = streaming kernel only
 static int g_decode_impl = -1;
+static unsigned long long* g_decode_trace = nullptr;
 static int decode_impl() {
   if (g_decode_impl < 0) g_decode_impl = getenv("MSGL_DECODE_IMPL") ? atoi(getenv("MSGL_DECODE_IMPL")) : 0;
   return g_decode_impl;
@@ -862,7 +889,7 @@ static int decode_impl() {
 static int mfma_variant(int G) {
   const int c = decode_impl();
   if (c >= 10 && c < 92) return c;
-  return G <= 2 && c != 92 ? 32 : 22;
+  return G <= 2 && c < 92 ? 32 : 22;
 }
 
 template <typename T, int G>
@@ -872,14 +899,15 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
 #define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW)                                                         \
   attn_decode_mfma_kernel<T, STAGES, WAVES, MINW>                                                     \
       <<<dim3((unsigned)((waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, s>>>(p)
-  switch (decode_impl() == 92 ? 92 : mfma_variant(G)) {
+  switch (decode_impl() >= 92 ? decode_impl() : mfma_variant(G)) {
     case 22: MSGL_MFMA_LAUNCH(2, 8, 2); break;
     case 23: MSGL_MFMA_LAUNCH(3, 8, 2); break;
     case 32: MSGL_MFMA_LAUNCH(2, 4, 3); break;
-    case 33: MSGL_MFMA_LAUNCH(3, 4, 3); break;
-    case 42: MSGL_MFMA_LAUNCH(2, 8, 4); break;
     case 92:
       attn_decode_mfma_kernel<T, 2, 8, 2, true><<<dim3((unsigned)((waves + 7) / 8)), dim3(512), 0, s>>>(p);
+      break;
+    case 93:  // variant 22 with clock stamps per wave (msgl_attn_decode_trace)
+      attn_decode_mfma_kernel<T, 2, 8, 2, false, true><<<dim3((unsigned)((waves + 7) / 8)), dim3(512), 0, s>>>(p);
       break;
 
     default: MSGL_MFMA_LAUNCH(4, 8, 2); break;
@@ -926,10 +954,15 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 33 || impl == 42 || impl == 92,
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 92 || impl == 93,
                "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
                "w waves per SIMD and s ring stages)", impl);
   g_decode_impl = impl;
+  return MSGL_OK;
+}
+
+extern "C" int msgl_attn_decode_trace(void* stamps) {
+  g_decode_trace = static_cast<unsigned long long*>(stamps);
   return MSGL_OK;
 }
 
@@ -1011,6 +1044,7 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
   p.group = group;
   p.slot_run = slot_run;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.trace = g_decode_trace;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (dtype == MSGL_BF16) rc = dispatch_group<BF16>(G, p, batch, capacity, s);

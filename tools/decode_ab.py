@@ -27,6 +27,7 @@ def main() -> None:
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--shape", default="14b")
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--scale", type=float, default=1.0, help="multiply every context length (marginal bandwidth)")
     ap.add_argument("--out", default="gpurun_out/decode_ab.json")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -34,7 +35,7 @@ def main() -> None:
     res = {}
     for shape in args.shape.split(","):
         B, hq, hkv = SHAPES[shape]
-        lens = bench_lens(B)
+        lens = [max(1, int(n * args.scale)) for n in bench_lens(B)]
         k, v, table, q = decode_case(B, hq, hkv, lens, 256, dev)
         D, cap = 128, max(4096, 2 * B)
         ws = torch.empty(ops.attn_decode_workspace_bytes(cap, hq, D), dtype=torch.uint8, device=dev)
