@@ -284,6 +284,38 @@ int msgl_m256_gemm_slabs_nt(const void* x, const void* w, int M, int N, int K, i
                             void* stream);
 
 /* ------------------------------------------------------------------------
+ * Native radix prefix tree (libmsgl_hip.so, csrc/radix.cpp; host code, no device work).
+ * Replaces: the tree walk of RadixPrefixCache -- _tree_walk, RadixTreeNode.split_at / get_match_len, lock_handle,
+ * evict, _collect_leave_nodes_for_evict (python/minisgl/kvcache/radix_cache.py:65-77, 111-130, 147-175, 189-230),
+ * which the reference runs in Python with one dict lookup, one tensor slice and one tvm-ffi call per node
+ * (SURVEY.md section 8f rank 4).  The tree owns keys (token ids), reference counts, timestamps and the two size counters;
+ * the VALUE tensors (pool slots, device memory) and the clock stay with the caller (mini-sglang_amd/radix.py), which
+ * mirrors each reported split / eviction on them.  Nodes are named by int64 ids (the root is id 0).
+ * Children are an insertion-ordered map and eviction is CPython's heapq over timestamps, so that every observable
+ * (matched lengths, handles, evicted slots, their order) equals the reference's for the same calls and clock.
+ *   create:     page_size = the scheduler's; now_ns stamps the root
+ *   walk:       out[5] = {node, matched length, split head id, split tail id, split position} (-1 x 3: no split);
+ *               stamps fully matched nodes with now_ns; a split cuts the tail's key (and must cut its value) at position
+ *   add_child:  new leaf under `parent` with key[n] (whole pages), stamped now_ns; evictable size += n; returns its id
+ *   lock:       lock_handle(node, unlock) along the path to the root
+ *   evict:      at least `size` tokens from unreferenced leaves, oldest first; out_ids = the evicted nodes in order
+ *               (their values, concatenated in this order, are what the reference's evict returns); returns the count
+ *   path:       node ids from below the root down to `node` (get_matched_indices concatenates their values)
+ *   info:       out[4] = {evictable, protected, live nodes, key length of `node` or -1}
+ *   check:      recomputes sizes and links (check_integrity)
+ * Errors: < 0 with msgl_last_error() (unknown / evicted node id, evict beyond the evictable size with the reference's
+ * message, ragged key). */
+int msgl_radix_create(void** tree, int page_size, int64_t now_ns);
+int msgl_radix_destroy(void* tree);
+int msgl_radix_walk(void* tree, const int32_t* ids, int64_t n, int64_t now_ns, int64_t* out);
+int64_t msgl_radix_add_child(void* tree, int64_t parent, const int32_t* key, int64_t n, int64_t now_ns);
+int msgl_radix_lock(void* tree, int64_t node, int unlock);
+int64_t msgl_radix_evict(void* tree, int64_t size, int64_t* out_ids, int64_t capacity);
+int64_t msgl_radix_path(void* tree, int64_t node, int64_t* out_ids, int64_t capacity);
+int msgl_radix_info(void* tree, int64_t node, int64_t* out);
+int msgl_radix_check(void* tree);
+
+/* ------------------------------------------------------------------------
  * Peer-to-peer collectives over xGMI for decode-size messages (libmsgl_hip.so, csrc/comm_p2p.hip).
  * What the reference gets from its symmetric buffer (ncclMemAlloc + ncclCommWindowRegister(
  * NCCL_WIN_COLL_SYMMETRIC), C/src/pynccl.cu:81-90) and NCCL's symmetric kernels (all_reduce through the

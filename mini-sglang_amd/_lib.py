@@ -77,6 +77,15 @@ HIP_SIGNATURES = {
     "msgl_p2p_get_buffer": (_p, [_p]),
     "msgl_p2p_destroy": (_i, [_p]),
     "msgl_p2p_release_all": (_i, []),
+    "msgl_radix_create": (_i, [C.POINTER(_p), _i, _l]),
+    "msgl_radix_destroy": (_i, [_p]),
+    "msgl_radix_walk": (_i, [_p, _p, _l, _l, _p]),
+    "msgl_radix_add_child": (_l, [_p, _l, _p, _l, _l]),
+    "msgl_radix_lock": (_i, [_p, _l, _i]),
+    "msgl_radix_evict": (_l, [_p, _l, _p, _l]),
+    "msgl_radix_path": (_l, [_p, _l, _p, _l]),
+    "msgl_radix_info": (_i, [_p, _l, _p]),
+    "msgl_radix_check": (_i, [_p]),
     "msgl_m256_gemm_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "msgl_m256_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
     "msgl_m256_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),

@@ -29,6 +29,7 @@ ARCH = "gfx950"
 
 HIP_SOURCES = [
     "host.cpp",
+    "radix.cpp",
     "store_index.hip",
     "norm_rope_act.hip",
     "attn_decode.hip",

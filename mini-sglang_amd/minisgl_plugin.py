@@ -267,15 +267,42 @@ def _install_deterministic_decode_order() -> None:
     DecodeManager.schedule_next_batch = schedule_next_batch
 
 
+# ------------------------------------------------------------------------------ native radix prefix cache
+def _install_native_radix(replace_radix: bool) -> None:
+    """Cache type "hip_radix" in the reference's registry (P/kvcache/__init__.py:23,59-64): RadixPrefixCache with the
+    tree walk in native code (radix.py, csrc/radix.cpp).  replace_radix=True also points the name "radix" (the
+    scheduler's default, BASELINE configs 2-3) at it."""
+    import minisgl.kvcache as kvc
+    from minisgl.core import get_global_ctx
+    from minisgl.kvcache.base import BaseCacheHandle, BasePrefixCache, InsertResult, MatchResult, SizeInfo
+
+    from .radix import make_prefix_cache_class
+
+    if "hip_radix" not in kvc.SUPPORTED_CACHE_MANAGER.supported_names():
+        cache_cls, _ = make_prefix_cache_class(BasePrefixCache, BaseCacheHandle, MatchResult, InsertResult, SizeInfo,
+                                               lambda: get_global_ctx().page_size)
+        _STATE["native_radix_class"] = cache_cls
+
+        def create_native_radix(device):
+            return cache_cls(device=device)
+
+        kvc.SUPPORTED_CACHE_MANAGER.register("hip_radix")(create_native_radix)
+    if replace_radix:
+        reg = kvc.SUPPORTED_CACHE_MANAGER._registry
+        _STATE.setdefault("reference_radix_factory", reg["radix"])
+        reg["radix"] = reg["hip_radix"]
+
+
 def gemm_report() -> List[dict]:
     """What the last pre-capture search chose (one dict per (batch size, projection))."""
     return list(_STATE["gemm_report"])
 
 
 def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True,
-            gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False) -> None:
+            gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False, native_radix: bool = False) -> None:
     """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic").
-    deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices)."""
+    deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices).
+    native_radix: cache_type="radix" uses the native tree walk too (cache_type="hip_radix" always does)."""
     if stub_zmq:
         _stub_zmq()
     _install_flashinfer_shim()
@@ -311,3 +338,4 @@ def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention:
         _install_fused_attention()
     if deterministic_decode_order:
         _install_deterministic_decode_order()
+    _install_native_radix(replace_radix=native_radix)

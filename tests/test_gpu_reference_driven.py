@@ -238,6 +238,34 @@ def test_reference_driven_radix_chunked_prefill_and_repeats_tiny(dev, model_dirs
     assert agree >= 0.9 * total
 
 
+def test_reference_driven_native_radix_makes_the_same_schedule(dev, model_dirs):
+    """cache_type="hip_radix" (native tree walk, csrc/radix.cpp) under the reference's scheduler on the GPU: the same
+    prompts, greedy, produce the same batches -- cached lengths, KV block indices (out_loc, page-table rows), graph use --
+    logits and tokens as with the reference's own RadixPrefixCache, and the cache ends in the same state."""
+    mdir, _ = model_dirs("tiny")
+    recs = {}
+    for kind in ("radix", "hip_radix"):
+        kw = dict(page_size=16, max_running_req=8, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512,
+                  num_page_override=256, max_extend_tokens=64, cache_type=kind)
+        rounds = [dict(prompts=ps, sampling=[greedy(6)] * len(ps)) for ps in tiny_rounds()]
+        recs[kind] = refdrive.run_worker(dict(model="tiny", model_dir=mdir, llm_kwargs=kw, rounds=rounds, max_position=4096,
+                                              deterministic_decode_order=True))
+    a, b = recs["radix"], recs["hip_radix"]
+    assert a["integrity"] == b["integrity"] == "ok" and a["outputs"] == b["outputs"]
+    assert b["prefix_cache"] == "NativeRadixPrefixCache" and a["prefix_cache"] == "RadixPrefixCache"
+    assert len(a["forwards"]) == len(b["forwards"])
+    hits = 0
+    for i, (f, g) in enumerate(zip(a["forwards"], b["forwards"])):
+        for key in ("phase", "size", "padded_size", "rows", "cached_lens", "device_lens", "chunked", "graph"):
+            assert f[key] == g[key], (i, key, f[key], g[key])
+        for key in ("input_ids", "positions", "out_loc", "table"):
+            assert torch.equal(f[key], g[key]), (i, key)
+        assert torch.equal(f["summary"]["checksum"], g["summary"]["checksum"]), i
+        hits += any(c > 0 and not ch for c, ch in zip(f["cached_lens"], f["chunked"])) and f["phase"] == "prefill"
+    assert hits > 0, "no radix-cache hit happened"
+    assert (a["free_pages_end"], a["evictable_end"]) == (b["free_pages_end"], b["evictable_end"])
+
+
 # ------------------------------------------------------------------------------ (b) 16-request slice of the offline bench, 0.6B
 @pytest.mark.parametrize("page_size", [1, 256])
 def test_reference_driven_offline_bench_slice_qwen3_0p6b(dev, model_dirs, page_size):
