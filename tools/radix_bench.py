@@ -1,0 +1,93 @@
+"""Host time of the prefix-cache calls on the scheduler's step path: the reference's RadixPrefixCache (Python tree walk,
+one dict lookup + tensor slice + tvm-ffi compare per node) vs the native tree (csrc/radix.cpp), same request stream.
+
+    python tools/radix_bench.py <dir holding the reference's `minisgl` package>   (e.g. oracle/_ref)
+"""
+from __future__ import annotations
+
+import random
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, sys.argv[1] if len(sys.argv) > 1 else str(ROOT / "oracle" / "_ref"))
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+import mini_sglang_amd.minisgl_plugin as plugin  # noqa: E402
+
+plugin.install(gemm_tune="off")
+import minisgl.core as core  # noqa: E402
+from minisgl.core import Context  # noqa: E402
+from minisgl.kvcache import create_prefix_cache  # noqa: E402
+
+
+def stream(page_size: int, n_req: int, seed: int):
+    """Offline-bench-like prompts (100-1024 tokens) where 60 % share a page-aligned prefix with an earlier request
+    (multi-turn / system-prompt reuse), so that walks go several nodes deep and split nodes."""
+    rnd = random.Random(seed)
+    docs = []
+    for _ in range(n_req):
+        n = rnd.randint(100, 1024)
+        if docs and rnd.random() < 0.6:
+            base = rnd.choice(docs)
+            cut = rnd.randrange(0, len(base)) // page_size * page_size
+            ids = base[:cut] + [rnd.randrange(32000) for _ in range(max(1, n - cut))]
+        else:
+            ids = [rnd.randrange(32000) for _ in range(n)]
+        docs.append(ids)
+    return [torch.tensor(d, dtype=torch.int32) for d in docs]
+
+
+def run(kind: str, page_size: int, reqs) -> dict:
+    core._GLOBAL_CTX = None
+    core.set_global_ctx(Context(page_size))
+    cache = create_prefix_cache(torch.device("cpu"), kind)
+    t_match = t_insert = t_lock = 0.0
+    slot = 0
+    hit_tokens = 0
+    for ids in reqs:
+        t0 = time.perf_counter()
+        h = cache.match_prefix(ids[:-1]).cuda_handle
+        t1 = time.perf_counter()
+        cache.lock_handle(h)
+        t2 = time.perf_counter()
+        hit_tokens += h.cached_len
+        idx = torch.arange(slot, slot + len(ids), dtype=torch.int32)
+        slot += len(ids)
+        t3 = time.perf_counter()
+        cache.insert_prefix(ids, idx)
+        t4 = time.perf_counter()
+        cache.lock_handle(h, unlock=True)
+        t5 = time.perf_counter()
+        t_match += t1 - t0
+        t_lock += (t2 - t1) + (t5 - t4)
+        t_insert += t4 - t3
+    t0 = time.perf_counter()
+    ev = cache.evict(cache.size_info.evictable_size // 2)
+    t_evict = time.perf_counter() - t0
+    n = len(reqs)
+    return dict(kind=kind, page_size=page_size, requests=n, hit_tokens=hit_tokens, match_us=t_match / n * 1e6,
+                insert_us=t_insert / n * 1e6, lock_unlock_us=t_lock / n * 1e6, evict_half_ms=t_evict * 1e3, evicted=len(ev))
+
+
+def main() -> None:
+    for page_size in (1, 16, 256):
+        reqs = stream(page_size, 2000, 3)
+        runs = [run(kind, page_size, reqs) for kind in ("radix", "hip_radix", "hip_radix", "radix", "radix", "hip_radix")]
+        res = []
+        for kind in ("radix", "hip_radix"):   # best of three per kind (allocator warm-up, other load on the host)
+            mine = [r for r in runs if r["kind"] == kind]
+            best = dict(mine[0])
+            for key in ("match_us", "insert_us", "lock_unlock_us", "evict_half_ms"):
+                best[key] = min(r[key] for r in mine)
+            res.append(best)
+        assert res[0]["hit_tokens"] == res[1]["hit_tokens"] and res[0]["evicted"] == res[1]["evicted"]
+        for r in res:
+            print({k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items()})
+
+
+if __name__ == "__main__":
+    main()
