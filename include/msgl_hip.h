@@ -129,6 +129,17 @@ int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const void* q_norm_
                             int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
                             int64_t q_stride, int64_t k_stride, int64_t v_stride,
                             int64_t cache_stride, int dtype, void* stream);
+/* The same pass for a qkv row that is still a split-K projection's partial sums (msgl_m256_gemm_slabs_nt):
+ * element = round16(sum_s slabs[s]) in slab order, then exactly msgl_qk_norm_rope_store on the [num_tokens,
+ * (Hq + 2 Hk) D] buffer `qkv` (q | k | v column blocks, row stride qkv_stride), which receives q, k AND v, i.e. ends
+ * up bit-identical to reduce-then-msgl_qk_norm_rope_store.  One launch less per layer. */
+int msgl_qk_norm_rope_store_slabs(void* qkv, int64_t qkv_stride, const float* slabs, int num_slabs,
+                                  int64_t slab_stride, int64_t slab_ld, const void* q_norm_w,
+                                  const void* k_norm_w, float eps, const void* positions,
+                                  int positions_is_i64, const float* cos_sin_cache, void* k_cache,
+                                  void* v_cache, const void* out_loc, int out_loc_is_i64,
+                                  int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
+                                  int64_t cache_stride, int dtype, void* stream);
 
 /* out[t, j] = silu(x[t, j]) * x[t, d + j].  Replaces flashinfer.silu_and_mul
  * (P/layers/activation.py:9-12). */

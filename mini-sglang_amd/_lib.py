@@ -45,6 +45,10 @@ HIP_SIGNATURES = {
         _i,
         [_p, _p, _p, _p, _p, _f, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _l, _l, _l, _l, _i, _p],
     ),
+    "msgl_qk_norm_rope_store_slabs": (
+        _i,
+        [_p, _l, _p, _i, _l, _l, _p, _p, _f, _p, _i, _p, _p, _p, _p, _i, _l, _i, _i, _i, _l, _i, _p],
+    ),
     "msgl_silu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_gelu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_attn_decode_select": (_i, [_i]),

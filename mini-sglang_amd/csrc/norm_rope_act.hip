@@ -184,13 +184,18 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
 // Fused pass over one token's qkv row: [rmsnorm per head] -> NeoX RoPE -> write q,k in
 // place, scatter k,v to the pool.  LPR = head_dim/8 lanes own one (token, head).
 // ------------------------------------------------------------------------------
-template <typename T, int LPR, typename PosT, typename LocT>
+// SLABS: the qkv row has not been written yet -- the qkv projection left `n_slabs` fp32 k-slice sums of it (slab s at
+// slabs + s * slab_stride, row stride slab_ld, columns in qkv order).  A piece is their sum in slab order rounded to
+// the 16-bit type, i.e. exactly what the projection's reduce kernel would have stored; v is then written in place as
+// well, so that the qkv buffer ends up bit-identical to the two-kernel path.
+template <typename T, int LPR, typename PosT, typename LocT, bool SLABS = false>
 __global__ __launch_bounds__(256) void qk_norm_rope_store_kernel(
-    uint16_t* __restrict__ q, uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    uint16_t* __restrict__ q, uint16_t* __restrict__ k, uint16_t* __restrict__ v,
     const uint16_t* __restrict__ qw, const uint16_t* __restrict__ kw, float eps,
     const PosT* __restrict__ positions, const float* __restrict__ cache, uint16_t* __restrict__ kc,
     uint16_t* __restrict__ vc, const LocT* __restrict__ out_loc, int64_t groups, int hq, int hk,
-    int64_t qs, int64_t ks, int64_t vs, int64_t cs) {
+    int64_t qs, int64_t ks, int64_t vs, int64_t cs, const float* __restrict__ slabs = nullptr, int n_slabs = 0,
+    int64_t slab_stride = 0, int64_t slab_ld = 0) {
   constexpr int D = LPR * 8;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t grp = gid / LPR;
@@ -200,10 +205,28 @@ __global__ __launch_bounds__(256) void qk_norm_rope_store_kernel(
   const int per_tok = hq + 2 * hk;
   const int64_t t = g / per_tok;
   const int head = (int)(g - t * per_tok);
+  auto piece = [&](const uint16_t* src) -> U4 {  // this lane's 8 elements of the projected row
+    if constexpr (SLABS) {
+      const float* sp = slabs + t * slab_ld + (int64_t)head * D + c * 8;
+      float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+      for (int sl = 1; sl < n_slabs; ++sl) {
+        const float* r = sp + (int64_t)sl * slab_stride;
+        const float4 a2 = *reinterpret_cast<const float4*>(r), b2 = *reinterpret_cast<const float4*>(r + 4);
+        a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+        b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+      }
+      const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      return pack8<T>(f);
+    } else {
+      return ldg16(src);
+    }
+  };
   if (head >= hq + hk) {  // V head: plain copy into the pool
     const int h = head - hq - hk;
     if (live) {
-      const U4 val = ldg16(v + t * vs + (int64_t)h * D + c * 8);
+      uint16_t* vp = v + t * vs + (int64_t)h * D + c * 8;
+      const U4 val = piece(vp);
+      if constexpr (SLABS) stg16(vp, val);
       stg16(vc + (int64_t)out_loc[t] * cs + (int64_t)h * D + c * 8, val);
     }
     return;  // whole LPR-lane group leaves together; DPP below only spans such groups
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_store_kernel(
                      : k + t * ks + (int64_t)(head - hq) * D + c * 8;
   const uint16_t* w = is_q ? qw : kw;
   float x[8];
-  unpack8<T>(ldg16(p), x);
+  unpack8<T>(piece(p), x);
   if (w != nullptr) {
     float ss = 0.f;
 #pragma unroll
@@ -429,13 +452,13 @@ extern "C" int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, i
   return act_and_mul<true>("gelu_and_mul", out, x, num_tokens, d, x_stride, out_stride, dtype, stream);
 }
 
-extern "C" int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const void* q_norm_w,
-                                       const void* k_norm_w, float eps, const void* positions,
-                                       int positions_is_i64, const float* cos_sin_cache, void* k_cache,
-                                       void* v_cache, const void* out_loc, int out_loc_is_i64,
-                                       int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
-                                       int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                       int64_t cache_stride, int dtype, void* stream) {
+static int qk_norm_rope_store_impl(void* q, void* k, void* v, const void* q_norm_w, const void* k_norm_w, float eps,
+                                   const void* positions, int positions_is_i64, const float* cos_sin_cache,
+                                   void* k_cache, void* v_cache, const void* out_loc, int out_loc_is_i64,
+                                   int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
+                                   int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t cache_stride,
+                                   int dtype, void* stream, const float* slabs, int n_slabs, int64_t slab_stride,
+                                   int64_t slab_ld) {
   MSGL_REQUIRE(num_tokens >= 0, "qk_norm_rope_store: negative token count");
   if (num_tokens == 0) return MSGL_OK;
   MSGL_REQUIRE(q && k && v && positions && cos_sin_cache && k_cache && v_cache && out_loc,
@@ -455,11 +478,17 @@ extern "C" int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const vo
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
-#define MSGL_QKRS(LPR, PT, LT)                                                                         \
-  qk_norm_rope_store_kernel<T, LPR, PT, LT><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(             \
-      (uint16_t*)q, (uint16_t*)k, (const uint16_t*)v, (const uint16_t*)q_norm_w, (const uint16_t*)k_norm_w, \
+#define MSGL_QKRS_S(LPR, PT, LT, SL)                                                                   \
+  qk_norm_rope_store_kernel<T, LPR, PT, LT, SL><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(         \
+      (uint16_t*)q, (uint16_t*)k, (uint16_t*)v, (const uint16_t*)q_norm_w, (const uint16_t*)k_norm_w, \
       eps, (const PT*)positions, cos_sin_cache, (uint16_t*)k_cache, (uint16_t*)v_cache, (const LT*)out_loc, \
-      groups, num_q_heads, num_k_heads, q_stride, k_stride, v_stride, cache_stride)
+      groups, num_q_heads, num_k_heads, q_stride, k_stride, v_stride, cache_stride, slabs, n_slabs,    \
+      slab_stride, slab_ld)
+#define MSGL_QKRS(LPR, PT, LT)                 \
+  do {                                         \
+    if (slabs) MSGL_QKRS_S(LPR, PT, LT, true); \
+    else MSGL_QKRS_S(LPR, PT, LT, false);      \
+  } while (0)
 #define MSGL_QKRS_L(LPR)                                                  \
   do {                                                                    \
     if (positions_is_i64) {                                               \
@@ -473,9 +502,44 @@ extern "C" int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const vo
     if (lpr == 16) MSGL_QKRS_L(16); else MSGL_QKRS_L(8);
 #undef MSGL_QKRS_L
 #undef MSGL_QKRS
+#undef MSGL_QKRS_S
     return MSGL_OK;
   });
   if (rc != MSGL_OK) return rc;
   MSGL_CHECK_LAUNCH("qk_norm_rope_store");
   return MSGL_OK;
+}
+
+extern "C" int msgl_qk_norm_rope_store(void* q, void* k, const void* v, const void* q_norm_w,
+                                       const void* k_norm_w, float eps, const void* positions,
+                                       int positions_is_i64, const float* cos_sin_cache, void* k_cache,
+                                       void* v_cache, const void* out_loc, int out_loc_is_i64,
+                                       int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
+                                       int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                       int64_t cache_stride, int dtype, void* stream) {
+  return qk_norm_rope_store_impl(q, k, const_cast<void*>(v), q_norm_w, k_norm_w, eps, positions, positions_is_i64,
+                                 cos_sin_cache, k_cache, v_cache, out_loc, out_loc_is_i64, num_tokens, num_q_heads,
+                                 num_k_heads, head_dim, q_stride, k_stride, v_stride, cache_stride, dtype, stream, nullptr,
+                                 0, 0, 0);
+}
+
+extern "C" int msgl_qk_norm_rope_store_slabs(void* qkv, int64_t qkv_stride, const float* slabs, int num_slabs,
+                                             int64_t slab_stride, int64_t slab_ld, const void* q_norm_w,
+                                             const void* k_norm_w, float eps, const void* positions,
+                                             int positions_is_i64, const float* cos_sin_cache, void* k_cache,
+                                             void* v_cache, const void* out_loc, int out_loc_is_i64,
+                                             int64_t num_tokens, int num_q_heads, int num_k_heads, int head_dim,
+                                             int64_t cache_stride, int dtype, void* stream) {
+  MSGL_REQUIRE(qkv && slabs, "qk_norm_rope_store_slabs: null pointer");
+  const int64_t width = (int64_t)(num_q_heads + 2 * num_k_heads) * head_dim;
+  MSGL_REQUIRE(num_slabs >= 1 && num_slabs <= 64 && slab_ld >= width && slab_ld % 4 == 0 && slab_stride % 4 == 0 &&
+                   aligned16(slabs) && qkv_stride >= width,
+               "qk_norm_rope_store_slabs: %d slabs, ld %lld, stride %lld, row %lld", num_slabs, (long long)slab_ld,
+               (long long)slab_stride, (long long)qkv_stride);
+  uint16_t* base = static_cast<uint16_t*>(qkv);
+  return qk_norm_rope_store_impl(base, base + (int64_t)num_q_heads * head_dim,
+                                 base + (int64_t)(num_q_heads + num_k_heads) * head_dim, q_norm_w, k_norm_w, eps, positions,
+                                 positions_is_i64, cos_sin_cache, k_cache, v_cache, out_loc, out_loc_is_i64, num_tokens,
+                                 num_q_heads, num_k_heads, head_dim, qkv_stride, qkv_stride, qkv_stride, cache_stride, dtype,
+                                 stream, slabs, num_slabs, slab_stride, slab_ld);
 }

@@ -125,6 +125,8 @@ def _install_fused_attention() -> None:
         ctx = get_global_ctx()
         backend = ctx.attn_backend
         if not isinstance(backend, HipAttnBackend) or not qkv.is_cuda:
+            if getattr(qkv, "_msgl_slabs", None) is not None:
+                raise RuntimeError("qkv_proj deferred its reduce to the fused attention pass, but the backend is not 'hip'")
             return reference_forward(self, qkv)
         batch = ctx.batch
         D = self.head_dim
@@ -132,9 +134,17 @@ def _install_fused_attention() -> None:
         kv = ctx.kv_cache
         kc, vc = kv.k_cache(self.layer_id), kv.v_cache(self.layer_id)
         qn, kn = self.q_norm, self.k_norm
-        ops.qk_norm_rope_store(q, k, v, qn.weight if qn is not None else None, kn.weight if kn is not None else None,
-                               qn.eps if qn is not None else 0.0, batch.positions, self.rotary._cos_sin_cache,
-                               kc.view(-1, self.kv_attn_dim), vc.view(-1, self.kv_attn_dim), batch.out_loc, D)
+        slabs = getattr(qkv, "_msgl_slabs", None)  # qkv_proj's F.linear left its split-K reduce to this pass
+        if slabs is not None:
+            del qkv._msgl_slabs
+            ops.qk_norm_rope_store_slabs(qkv, slabs, self.num_qo_heads, self.num_kv_heads,
+                                         qn.weight if qn is not None else None, kn.weight if kn is not None else None,
+                                         qn.eps if qn is not None else 0.0, batch.positions, self.rotary._cos_sin_cache,
+                                         kc.view(-1, self.kv_attn_dim), vc.view(-1, self.kv_attn_dim), batch.out_loc, D)
+        else:
+            ops.qk_norm_rope_store(q, k, v, qn.weight if qn is not None else None, kn.weight if kn is not None else None,
+                                   qn.eps if qn is not None else 0.0, batch.positions, self.rotary._cos_sin_cache,
+                                   kc.view(-1, self.kv_attn_dim), vc.view(-1, self.kv_attn_dim), batch.out_loc, D)
         o = backend.attend(q.view(-1, self.num_qo_heads, D), self.layer_id, batch)
         return o.view(-1, self.qo_attn_dim)
 
@@ -191,8 +201,16 @@ def _norm_fed_weights(model: Any) -> set:
     layer's down_proj feeds the final norm, qwen3.py:63) when no all-reduce sits in between (tp = 1).  Recognised
     structurally; anything that does not look exactly like that layer is left alone."""
     from minisgl.layers.base import BaseOP
-    from minisgl.layers.linear import LinearOProj, LinearRowParallel
+    from minisgl.core import get_global_ctx
+    from minisgl.layers.linear import LinearOProj, LinearQKVMerged, LinearRowParallel
     from minisgl.layers.norm import RMSNormFused
+
+    from .attention import HipAttnBackend
+
+    try:
+        hip_backend = isinstance(get_global_ctx().attn_backend, HipAttnBackend)
+    except Exception:
+        hip_backend = False
     from minisgl.models.utils import GatedMLP, RopeAttn
 
     ptrs: set = set()
@@ -206,6 +224,12 @@ def _norm_fed_weights(model: Any) -> set:
             if (type(o) is LinearOProj and type(down) is LinearRowParallel and o.bias is None and down.bias is None
                     and o._tp_size == 1 and down._tp_size == 1 and o.weight.is_cuda):
                 ptrs.update((o.weight.data_ptr(), down.weight.data_ptr()))
+            # qkv_proj -> AttentionLayer.forward (P/models/utils.py:118-123), column-parallel: any tp size; only when
+            # that forward is the fused one installed above and the backend is ours
+            qkv = getattr(attn, "qkv_proj", None)
+            if (type(qkv) is LinearQKVMerged and qkv.bias is None and qkv.weight.is_cuda and _STATE["fused_attention"]
+                    and hip_backend):
+                ptrs.add(qkv.weight.data_ptr())
             return
         if isinstance(op, BaseOP):
             for sub in vars(op).values():

@@ -279,13 +279,19 @@ class DenseDecoder:
                 x = fi.rmsnorm(x, lw.input_norm, cfg.rms_norm_eps)
             else:
                 fi.fused_add_rmsnorm(x, residual, lw.input_norm, cfg.rms_norm_eps)
-            qkv = ops.linear(x, lw.qkv)
+            # a k-sliced full-batch plan leaves the qkv projection's reduce to the fused norm / RoPE / store pass
+            qkv, slabs = ops.linear_slabs(x, lw.qkv) if self.fused and _SLAB_NORM else (ops.linear(x, lw.qkv), None)
             q, k, v = qkv.split([self.q_dim, self.kv_dim, self.kv_dim], dim=-1)
             if self.fused:
                 kc, vc = kv.k_cache(li), kv.v_cache(li)
-                ops.qk_norm_rope_store(q, k, v, lw.q_norm, lw.k_norm, cfg.rms_norm_eps, batch.positions,
-                                       self.cos_sin, kc.view(-1, self.kv_dim), vc.view(-1, self.kv_dim),
-                                       batch.out_loc, D)
+                if slabs is not None:
+                    ops.qk_norm_rope_store_slabs(qkv, slabs, self.hq, self.hkv, lw.q_norm, lw.k_norm, cfg.rms_norm_eps,
+                                                 batch.positions, self.cos_sin, kc.view(-1, self.kv_dim),
+                                                 vc.view(-1, self.kv_dim), batch.out_loc, D)
+                else:
+                    ops.qk_norm_rope_store(q, k, v, lw.q_norm, lw.k_norm, cfg.rms_norm_eps, batch.positions,
+                                           self.cos_sin, kc.view(-1, self.kv_dim), vc.view(-1, self.kv_dim),
+                                           batch.out_loc, D)
                 o = backend.attend(q.view(-1, self.hq, D), li, batch)
             else:  # P/layers/attention.py:47-57
                 if lw.q_norm is not None:

@@ -159,7 +159,8 @@ _PENDING_SLABS: dict = {}
 def _no_pending_slabs(device: torch.device) -> None:
     if _PENDING_SLABS and _PENDING_SLABS.get(device.index or 0) is not None:
         raise RuntimeError("a split-K projection's partial sums are still waiting for fused_add_rmsnorm_slabs: "
-                           "linear_slabs() output was handed to a different consumer")
+                           "linear_slabs() output was handed to a different consumer (not fused_add_rmsnorm_slabs / "
+                           "qk_norm_rope_store_slabs)")
 
 
 def fused_add_rmsnorm_slabs(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
@@ -215,6 +216,31 @@ def qk_norm_rope_store(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_norm
             head_dim, q.stride(0), k.stride(0), v.stride(0), k_cache.stride(0), _dt(q), _stream(),
         ),
         "qk_norm_rope_store",
+    )
+
+
+def qk_norm_rope_store_slabs(qkv: torch.Tensor, slabs: "Slabs", num_q_heads: int, num_k_heads: int,
+                             q_norm_w: Optional[torch.Tensor], k_norm_w: Optional[torch.Tensor], eps: float,
+                             positions: torch.Tensor, cos_sin_cache: torch.Tensor, k_cache: torch.Tensor,
+                             v_cache: torch.Tensor, out_loc: torch.Tensor, head_dim: int) -> None:
+    """qk_norm_rope_store for a qkv = linear_slabs(...) output whose k-slice sums are still in `slabs`: the reduce
+    happens here; qkv receives q, k and v."""
+    _need_cuda(qkv, positions, cos_sin_cache, k_cache, v_cache, out_loc)
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape == (slabs.rows, slabs.dim)
+    assert qkv.shape[1] == (num_q_heads + 2 * num_k_heads) * head_dim
+    assert k_cache.dim() == 2 and k_cache.shape[1] == num_k_heads * head_dim and k_cache.stride(0) == v_cache.stride(0)
+    if _PENDING_SLABS.get(slabs.device) is not slabs:
+        raise RuntimeError("qk_norm_rope_store_slabs: these partial sums are no longer the workspace's content")
+    _PENDING_SLABS[slabs.device] = None
+    check(
+        lib().msgl_qk_norm_rope_store_slabs(
+            qkv.data_ptr(), qkv.stride(0), slabs.ptr, slabs.count, slabs.rows * slabs.dim, slabs.dim,
+            q_norm_w.data_ptr() if q_norm_w is not None else None,
+            k_norm_w.data_ptr() if k_norm_w is not None else None, float(eps), positions.data_ptr(),
+            _is_i64(positions), cos_sin_cache.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out_loc.data_ptr(),
+            _is_i64(out_loc), qkv.shape[0], num_q_heads, num_k_heads, head_dim, k_cache.stride(0), _dt(qkv), _stream(),
+        ),
+        "qk_norm_rope_store_slabs",
     )
 
 

@@ -299,3 +299,38 @@ def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, 
     finally:
         ops._M256_PLAN.clear()
         ops._PENDING_SLABS.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,hq,hk,D,K,split,qk_norm", [(256, 40, 8, 128, 5120, 4, True), (160, 16, 8, 128, 1024, 4, True),
+                                                     (130, 8, 2, 64, 512, 2, False)])
+def test_split_k_reduce_folded_into_qk_norm_rope_store(ops, dev, dtype, M, hq, hk, D, K, split, qk_norm):
+    """qkv_proj -> (q-norm, k-norm, RoPE, KV store) with the projection's slab reduce done by the fused pass: the whole
+    qkv buffer (q, k AND v) and both pools bit-identical to reduce-then-qk_norm_rope_store."""
+    g = torch.Generator(device=dev).manual_seed(M + hq + K)
+    N = (hq + 2 * hk) * D
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(dtype)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(dtype)
+    qw = (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(dtype) if qk_norm else None
+    kw = (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(dtype) if qk_norm else None
+    pos = torch.randint(0, 4096, (M,), generator=g, device=dev, dtype=torch.int32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, device=dev, dtype=torch.float32) / D))
+    ang = torch.arange(4096, device=dev, dtype=torch.float32)[:, None] * inv[None, :]
+    cos_sin = torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+    loc = torch.randperm(1024, generator=g, device=dev)[:M].to(torch.int32)
+    key = (dev.index or 0, M, N, K, x.stride(0), w.stride(0), ops._dt(x))
+    ops._M256_PLAN[key] = (256, 0, split)
+    try:
+        qkv_ref = ops.linear(x, w)
+        kc_ref, vc_ref = (torch.zeros((1024, hk * D), dtype=dtype, device=dev) for _ in range(2))
+        q, k, v = qkv_ref.split([hq * D, hk * D, hk * D], dim=-1)
+        ops.qk_norm_rope_store(q, k, v, qw, kw, 1e-6, pos, cos_sin, kc_ref, vc_ref, loc, D)
+        qkv, slabs = ops.linear_slabs(x, w)
+        assert slabs is not None and slabs.count == split
+        kc, vc = (torch.zeros((1024, hk * D), dtype=dtype, device=dev) for _ in range(2))
+        ops.qk_norm_rope_store_slabs(qkv, slabs, hq, hk, qw, kw, 1e-6, pos, cos_sin, kc, vc, loc, D)
+        assert torch.equal(qkv, qkv_ref) and torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+        ops.linear(x, w)   # the workspace is free again
+    finally:
+        ops._M256_PLAN.clear()
+        ops._PENDING_SLABS.clear()

@@ -297,9 +297,9 @@ def test_reference_driven_offline_bench_slice_qwen3_0p6b(dev, model_dirs, page_s
 
 # ------------------------------------------------------------------------------ (c) full-batch GEMM + reduce-in-norm through the reference's layers
 def test_reference_driven_split_k_projection_reduced_by_the_next_norm(dev, model_dirs, monkeypatch):
-    """o_proj / down_proj of the reference's decoder layer (P/models/qwen3.py:37-41) through the plugin at a decode
-    batch of 160: `F.linear` runs the k-sliced full-batch kernel WITHOUT its reduce launch and the reference's
-    RMSNormFused -> fused_add_rmsnorm adds the slabs.  The repo engine, replaying the same batches with the same
+    """o_proj / down_proj / qkv_proj of the reference's decoder layer (P/models/qwen3.py:37-41, utils.py:118-123) through
+    the plugin at a decode batch of 160: `F.linear` runs the k-sliced full-batch kernel WITHOUT its reduce launch; the
+    reference's RMSNormFused -> fused_add_rmsnorm adds the slabs of o / down, the fused AttentionLayer.forward those of qkv.  The repo engine, replaying the same batches with the same
     plans but a separate reduce kernel, must produce the same bits."""
     from mini_sglang_amd import model as model_mod
     from mini_sglang_amd import ops
@@ -308,12 +308,12 @@ def test_reference_driven_split_k_projection_reduced_by_the_next_norm(dev, model
     B = 160
     rnd = random.Random(5)
     prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(4, 40))] for _ in range(B)]
-    plans = [[B, 1024, 2048, 256, 0, 8], [B, 1024, 3072, 256, 0, 12]]
+    plans = [[B, 1024, 2048, 256, 0, 8], [B, 1024, 3072, 256, 0, 12], [B, 4096, 1024, 256, 0, 4]]   # o, down, qkv
     kw = dict(page_size=16, max_running_req=B, cuda_graph_bs=[B], max_seq_len_override=256,
               num_page_override=4096, max_extend_tokens=8192, cache_type="radix")
     rec = refdrive.run_worker(dict(model="qwen3-0.6b", model_dir=mdir, llm_kwargs=kw, m256_plans=plans,
                                    rounds=[dict(prompts=prompts, sampling=[greedy(6)] * B)]))
-    assert rec["integrity"] == "ok" and rec["norm_fed_weights"] == 2 * 28
+    assert rec["integrity"] == "ok" and rec["norm_fed_weights"] == 3 * 28
     dec = [f for f in rec["forwards"] if f["phase"] == "decode" and f["size"] == B]
     assert len(dec) >= 4 and all(f["graph"] for f in dec)
     code = ops._dt(torch.empty(0, dtype=torch.bfloat16))
