@@ -359,6 +359,7 @@ def main() -> None:
                         f"distribution (mean {S / B:.0f}), page_size {args.page_size}, temperature 0.6, hipGraph "
                         f"{'on' if use_graph else 'off'}",
             "batch": B, "parallelism": f"tp{world}", "mean_context": S / B,
+            "collectives": None if world == 1 else ("p2p (decode-size) + rccl" if comm.p2p is not None else "rccl"),
         },
         "ttft_p50_ms": ttft_p50,
         "small_batch_ms_per_step": small,

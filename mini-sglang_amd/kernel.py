@@ -85,14 +85,71 @@ class P2PCommunicator:
         self._lib = _lib.lib()
         self._handle = ctypes.c_void_p()
         self.rank, self.world_size, self.max_bytes = rank, world_size, int(max_bytes)
-        _lib.check(self._lib.msgl_p2p_create(ctypes.byref(self._handle), rank, world_size, self.max_bytes), "p2p_create")
-        mine = ctypes.create_string_buffer(_lib.IPC_HANDLE_BYTES)
-        _lib.check(self._lib.msgl_p2p_ipc_handle(self._handle, mine), "p2p_ipc_handle")
+        # every step that can fail on ONE rank (allocation, handle export, mapping a peer's buffer) is followed by an
+        # exchange over the CPU group, so that all ranks learn of it and raise together instead of one raising while
+        # the others wait in a collective
+        mine, err = None, None
+        try:
+            _lib.check(self._lib.msgl_p2p_create(ctypes.byref(self._handle), rank, world_size, self.max_bytes), "p2p_create")
+            buf = ctypes.create_string_buffer(_lib.IPC_HANDLE_BYTES)
+            _lib.check(self._lib.msgl_p2p_ipc_handle(self._handle, buf), "p2p_ipc_handle")
+            mine = buf.raw
+        except Exception as e:  # noqa: BLE001 - reported to every rank below
+            err = f"rank {rank}: {e}"
         handles = [None] * world_size
-        dist.all_gather_object(handles, mine.raw, group=cpu_group)
-        _lib.check(self._lib.msgl_p2p_open(self._handle, b"".join(handles)), "p2p_open")
-        _lib.check(self._lib.msgl_p2p_configure(self._handle, one_shot_max_bytes, blocks), "p2p_configure")
-        dist.barrier(group=cpu_group)  # every rank has mapped every buffer before the first collective
+        dist.all_gather_object(handles, (mine, err), group=cpu_group)
+        self._raise_if_any([h[1] for h in handles])
+        try:
+            _lib.check(self._lib.msgl_p2p_open(self._handle, b"".join(h[0] for h in handles)), "p2p_open")
+            _lib.check(self._lib.msgl_p2p_configure(self._handle, one_shot_max_bytes, blocks), "p2p_configure")
+        except Exception as e:  # noqa: BLE001
+            err = f"rank {rank}: {e}"
+        errs = [None] * world_size
+        dist.all_gather_object(errs, err, group=cpu_group)  # also: every rank has mapped every buffer before the first collective
+        self._raise_if_any(errs)
+
+    def _raise_if_any(self, errs) -> None:
+        bad = [e for e in errs if e]
+        if bad:
+            self.destroy()
+            raise RuntimeError("peer-to-peer communicator setup failed: " + "; ".join(bad))
+
+    def self_test(self, cpu_group) -> Optional[str]:
+        """Known answers (rank-valued data -> n(n+1)/2, tests/kernel/test_comm.py:106-114 of the reference) through the
+        one-shot and the two-shot kernel and the all-gather, on this communicator's real links.  Returns None if every
+        rank saw the right values and no barrier timed out, else a description -- the same on all ranks."""
+        import torch.distributed as dist
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        problems = []
+        try:
+            for name, numel in (("one-shot", 4096), ("two-shot", max(8192, (self.max_bytes // 2) // 16 * 8))):
+                if numel * 2 > self.max_bytes:
+                    continue
+                x = torch.full((numel,), float(self.rank + 1), dtype=torch.bfloat16, device=dev)
+                self.all_reduce(x)
+                torch.cuda.synchronize()
+                want = float(self.world_size * (self.world_size + 1) // 2)
+                if not bool((x == want).all()):
+                    problems.append(f"{name} all-reduce: got {x[:2].tolist()} .. {x[-2:].tolist()}, want {want}")
+            n = min(4096, self.max_bytes // 2 // self.world_size // 8 * 8)
+            if n > 0:
+                src = torch.full((n,), float(self.rank), dtype=torch.bfloat16, device=dev)
+                dst = torch.empty((n * self.world_size,), dtype=torch.bfloat16, device=dev)
+                self.all_gather(dst, src)
+                torch.cuda.synchronize()
+                want = torch.arange(self.world_size, device=dev, dtype=torch.bfloat16).repeat_interleave(n)
+                if not torch.equal(dst, want):
+                    problems.append("all-gather: wrong contents")
+            if self.error():
+                problems.append(f"barrier phase {self.error() - 1} timed out")
+        except Exception as e:  # noqa: BLE001
+            problems.append(f"{type(e).__name__}: {e}")
+        mine = f"rank {self.rank}: " + "; ".join(problems) if problems else None
+        everyone = [None] * self.world_size
+        dist.all_gather_object(everyone, mine, group=cpu_group)
+        bad = [e for e in everyone if e]
+        return "; ".join(bad) if bad else None
 
     def fits(self, t: torch.Tensor) -> bool:
         n = t.numel() * t.element_size()
@@ -184,7 +241,24 @@ def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int
         assert uid is not None, f"Failed to get RCCL unique ID on {tp_rank = }"
         rccl = RcclCommunicator(tp_rank, tp_size, 0, uid)
     if backend != "rccl" and max_size_bytes > 0 and tp_size <= 8:
-        p2p = P2PCommunicator(tp_rank, tp_size, tp_cpu_group, max_size_bytes)
+        # the mapped-buffer path is checked on the links it will run on before anything depends on it; with RCCL at
+        # hand a failure (setup or known answers) is reported and the library path carries all messages
+        problem = None
+        try:
+            p2p = P2PCommunicator(tp_rank, tp_size, tp_cpu_group, max_size_bytes)
+            problem = p2p.self_test(tp_cpu_group)
+        except RuntimeError as e:
+            problem = str(e)
+        if problem is not None:
+            if p2p is not None:
+                p2p.destroy()
+                p2p = None
+            if rccl is None:
+                raise RuntimeError(f"peer-to-peer collectives unusable and no RCCL communicator to fall back to: {problem}")
+            if tp_rank == 0:
+                import sys
+
+                print(f"[msgl] peer-to-peer collectives disabled, RCCL carries every message: {problem}", file=sys.stderr)
     return HybridCommunicator(p2p, rccl)
 
 
