@@ -235,6 +235,13 @@ class Engine:
         # solution search happens before capture (it synchronises); full search only where it pays
         self.gemm_report = self.model.tune_gemms(bs_list, cfg.gemm_tune)
         self.graph_runner = GraphRunner(self, bs_list)
+        if cfg.tp_size > 1 and cfg.tp_cpu_group is not None:
+            # kernel search and capture take a rank-dependent time; the device-side barriers of the peer-to-peer
+            # collectives spin for a bounded time only, so the ranks meet on the CPU before the first forward
+            import torch.distributed as dist
+
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=cfg.tp_cpu_group)
 
     def _agreed_free_memory(self, free: int) -> int:
         """Every TP rank must derive the same num_pages / max_seq_len / page-table width (the schedulers are

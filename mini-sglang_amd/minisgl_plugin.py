@@ -27,7 +27,7 @@ import types
 from typing import Any, Dict, List, Optional
 
 _STATE: Dict[str, Any] = {"gemm_tune": "heuristic", "gemm_report": [], "fast_linear": False, "fused_attention": False,
-                          "norm_fed_weights": set()}
+                          "deferred_reduce_weights": set()}
 
 
 def _stub_zmq() -> None:
@@ -90,9 +90,10 @@ class _FunctionalProxy:
                 and weight.dim() == 2 and x.dim() >= 1 and x.shape[-1] == weight.shape[1] and weight.stride(1) == 1):
             x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
             if x2.stride(1) == 1:
-                if x.dim() == 2 and weight.data_ptr() in _STATE["norm_fed_weights"]:
-                    # o_proj / down_proj of a dense decoder layer at tp = 1: the tensor returned here is the very
-                    # object RMSNormFused.forward passes to fused_add_rmsnorm, which then does the split-K reduce
+                if x.dim() == 2 and weight.data_ptr() in _STATE["deferred_reduce_weights"]:
+                    # o_proj / down_proj (tp = 1) or qkv_proj of a dense decoder layer: the tensor returned here is
+                    # the very object the reference hands to fused_add_rmsnorm (RMSNormFused.forward) resp. to
+                    # AttentionLayer.forward, which then does the split-K reduce
                     y, slabs = ops.linear_slabs(x2, weight)
                     if slabs is not None:
                         y._msgl_slabs = slabs
@@ -195,11 +196,13 @@ def _projection_groups(model: Any, require_device: bool = True) -> List[tuple]:
     return groups
 
 
-def _norm_fed_weights(model: Any) -> set:
-    """data_ptr of every projection weight whose output goes, untouched, into the next RMSNormFused's fused residual add:
-    o_proj and down_proj of the dense decoder layers (P/models/qwen3.py:37-41, llama.py:39-43, qwen2.py; the last
-    layer's down_proj feeds the final norm, qwen3.py:63) when no all-reduce sits in between (tp = 1).  Recognised
-    structurally; anything that does not look exactly like that layer is left alone."""
+def _deferred_reduce_weights(model: Any) -> set:
+    """data_ptr of every projection weight whose output goes, untouched, into a kernel of ours that can add the
+    projection's k-slice sums itself: o_proj and down_proj of the dense decoder layers into the next RMSNormFused's
+    fused residual add (P/models/qwen3.py:37-41, llama.py:39-43, qwen2.py; the last layer's down_proj feeds the final
+    norm, qwen3.py:63) when no all-reduce sits in between (tp = 1), and qkv_proj into AttentionLayer.forward
+    (P/models/utils.py:118-123).  Recognised structurally; anything that does not look exactly like that layer is left
+    alone."""
     from minisgl.layers.base import BaseOP
     from minisgl.core import get_global_ctx
     from minisgl.layers.linear import LinearOProj, LinearQKVMerged, LinearRowParallel
@@ -263,7 +266,7 @@ def _install_tune_before_capture() -> None:
                                                               self.device, log=log)
                 torch.cuda.synchronize(self.device)
         if _STATE["fast_linear"] and os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1":
-            _STATE["norm_fed_weights"] = _norm_fed_weights(model)
+            _STATE["deferred_reduce_weights"] = _deferred_reduce_weights(model)
         return reference_capture(self, max_seq_len, vocab_size, model)
 
     _capture_graphs._msgl_tuned = True  # type: ignore[attr-defined]

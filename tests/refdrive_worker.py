@@ -151,7 +151,7 @@ def main() -> None:
                graph_bs=list(engine.graph_runner.graph_bs_list), backend=type(engine.attn_backend).__name__,
                attention_forward_fused=bool(getattr(type(engine.model.model.layers.op_list[0].self_attn.attn).forward,
                                                     "_msgl_fused", False)),
-               gemm_report=plugin.gemm_report(), prefix_cache=type(cm.prefix_cache).__name__, norm_fed_weights=len(plugin._STATE["norm_fed_weights"]), free_pages_end=int(len(cm.free_slots)),
+               gemm_report=plugin.gemm_report(), prefix_cache=type(cm.prefix_cache).__name__, deferred_reduce_weights=len(plugin._STATE["deferred_reduce_weights"]), free_pages_end=int(len(cm.free_slots)),
                evictable_end=int(cm.prefix_cache.size_info.evictable_size), device=torch.cuda.get_device_name(0))
     try:
         cm.check_integrity()

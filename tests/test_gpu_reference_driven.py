@@ -313,7 +313,7 @@ def test_reference_driven_split_k_projection_reduced_by_the_next_norm(dev, model
               num_page_override=4096, max_extend_tokens=8192, cache_type="radix")
     rec = refdrive.run_worker(dict(model="qwen3-0.6b", model_dir=mdir, llm_kwargs=kw, m256_plans=plans,
                                    rounds=[dict(prompts=prompts, sampling=[greedy(6)] * B)]))
-    assert rec["integrity"] == "ok" and rec["norm_fed_weights"] == 3 * 28
+    assert rec["integrity"] == "ok" and rec["deferred_reduce_weights"] == 3 * 28
     dec = [f for f in rec["forwards"] if f["phase"] == "decode" and f["size"] == B]
     assert len(dec) >= 4 and all(f["graph"] for f in dec)
     code = ops._dt(torch.empty(0, dtype=torch.bfloat16))
