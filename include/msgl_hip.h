@@ -170,7 +170,12 @@ int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, i
  * min_chunk: smallest slot in tokens (power of two >= 16).  The plan buffer
  * must be 16-byte aligned; plan[0] = pieces, [1] = tokens per slot, [3] = slots.
  * ---------------------------------------------------------------------- */
-/* number of int32 words the plan buffer needs */
+/* number of int32 words the plan buffer needs  * Combining the split-KV partial sums: a merge kernel follows the partial kernel.  Alternative kept for measurement
+ * (msgl_attn_decode_select(72)): the piece of a request that arrives last (per-(request, kv head) arrival counters at
+ * the end of the plan buffer, zeroed by msgl_attn_decode_plan and left at zero by every launch) reads the others'
+ * partial sums -- published write-through -- and writes the output itself, in piece order with the merge kernel's
+ * arithmetic: same bits, one launch less, but not faster; msgl_attn_decode then WRITES those counters inside `plan`.
+ */
 int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);
 /* bytes of fp32 workspace for split-KV partials */
 int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim);
@@ -186,8 +191,9 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
 /* Which partial-attention kernel msgl_attn_decode_plan / msgl_attn_decode use from now on (process-wide; plan and
  * launch must be made under the same choice): 0 = default (matrix-core kernel for slot_run >= 16, streaming kernel
  * otherwise), 1 = streaming kernel only; for timing and diagnosis also 10 w + s = matrix-core kernel held to w waves
- * per SIMD with an s-stage request ring (22, 23, 24, 32), 92 = variant 22 with the products left out (what the
- * request pattern alone costs), 93 = variant 22 leaving clock stamps (msgl_attn_decode_trace).  Also settable by
+ * per SIMD with an s-stage request ring (22, 23, 24, 32), 72 = variant 22 with the in-kernel combine instead of
+ * the merge kernel, 92 = variant 22 with the products left out (what the request pattern alone costs), 93 =
+ * variant 22 leaving clock stamps (msgl_attn_decode_trace).  Also settable by
  * MSGL_DECODE_IMPL before the first call.  Both kernels meet the same tolerance against the oracle. */
 int msgl_attn_decode_select(int impl);
 /* Diagnosis: under msgl_attn_decode_select(93) every wave leaves 16 uint64 shader-clock stamps at stamps[16 * wave]:

@@ -64,13 +64,20 @@ constexpr float kNegBig = -3.0e38f;
 
 // plan buffer layout (int32 words):
 //   hdr[4] | item_start[max_bs] | n_chunks[max_bs] | tile_start[max_bs] | slot_first[capacity + 1] |
-//   items[4 * capacity] = (request, first tile, end tile, slot)
+//   items[4 * capacity] = (request, first tile, end tile, slot) | arrivals[max_bs * kTicketHeads]
+// arrivals[b][kv head]: how many pieces of request b have published their partial sums in the running launch (matrix-core
+// kernel under select code 72: the piece that arrives last combines them).  Zeroed by the plan kernel, left at zero by
+// every launch.
+constexpr int kTicketHeads = 64;
 __host__ __device__ inline int64_t plan_off_item_start() { return kPlanHdr; }
 __host__ __device__ inline int64_t plan_off_n_chunks(int max_bs) { return kPlanHdr + (int64_t)max_bs; }
 __host__ __device__ inline int64_t plan_off_tile_start(int max_bs) { return kPlanHdr + 2ll * max_bs; }
 __host__ __device__ inline int64_t plan_off_slot_first(int max_bs) { return kPlanHdr + 3ll * max_bs; }
 __host__ __device__ inline int64_t plan_off_items(int max_bs, int capacity) {
   return ((kPlanHdr + 3ll * max_bs + capacity + 1 + 3) / 4) * 4;  // int4-aligned
+}
+__host__ __device__ inline int64_t plan_off_arrivals(int max_bs, int capacity) {
+  return plan_off_items(max_bs, capacity) + 4ll * capacity;
 }
 
 // ------------------------------------------------------------------------------
@@ -166,6 +173,8 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan
     plan[3] = n_slots;
     slot_first[n_slots] = n_items;
   }
+  int* arrivals = plan + plan_off_arrivals(max_bs, capacity);
+  for (int i = tid; i < max_bs * kTicketHeads; i += 256) arrivals[i] = 0;
 }
 
 // ------------------------------------------------------------------------------
@@ -187,6 +196,7 @@ struct DecodeParams {
   int slot_run;               // aligned runs of this many positions map to consecutive slots (1: none)
   float scale_log2;
   unsigned long long* trace;  // diagnosis (msgl_attn_decode_trace): 16 clock stamps per wave, else nullptr
+  int* arrivals;              // plan_off_arrivals: per (request, kv head) arrival counters of the matrix-core kernel
 };
 
 struct Tile {
@@ -588,7 +598,8 @@ __device__ __forceinline__ int vimg_off(int tok, int byte_in_row) {
 // hv = 8); kMinW: waves per SIMD the register budget is held to
 // kLoadsOnly (diagnosis, variant 92): the same requests and waits with the products left out -- what the request
 // pattern alone costs
-template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false, bool kTrace = false>
+template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false, bool kTrace = false,
+          bool kCombine = false>
 __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kernel(const DecodeParams p) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * 4096];
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
 #pragma unroll
   for (int db = 0; db < 8; ++db) rd_off[db] = vimg_off(4 * qd + (tok >> 2), db * 32 + (tok & 3) * 8);
 
+  const __amdgpu_buffer_rsrc_t part_rsrc = make_rsrc(p.part_o);  // the fp32 partial sums (offsets < 2^31: checked at launch)
   mark();  // 1: slot known
   for (int item = item_begin; item < item_end; ++item) {
     const int4 it = items[item];
@@ -631,7 +643,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
     const int t0 = sgpr(it.y) * 16;
     const int t1 = min(S, sgpr(it.z) * 16);
     const int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
-    const bool single = sgpr(n_chunks[b]) == 1;  // read here, with the rest of the metadata, not on the way out
+    const int nch = sgpr(n_chunks[b]);  // read here, with the rest of the metadata, not on the way out
+    const int first_item = sgpr(p.plan[plan_off_item_start() + b]);
+    const bool single = nch == 1;
     const CInt* cpt = (const CInt*)(p.page_table + (int64_t)row * p.pt_stride);
     const int hq0 = h * G;
     const int kvh = hq0 / p.group;
@@ -757,7 +771,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
           u.y = Elem<T>::pack(o[db][2] * inv, o[db][3] * inv);
           *reinterpret_cast<uint2*>(op + db * 16) = u;
         }
-      } else {
+      } else if constexpr (!kCombine) {
         float* po = p.part_o + ((int64_t)item * p.hq + hq) * D + 4 * qd;
 #pragma unroll
         for (int db = 0; db < 8; ++db)
@@ -765,6 +779,72 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
         if (qd == 0) {
           float* pm = p.part_ml + ((int64_t)item * p.hq + hq) * 2;
           *reinterpret_cast<float2*>(pm) = make_float2(m, l);
+        }
+      } else {
+        // publish write-through (sc1): the partial sums are complete in memory once this wave's vmcnt drains, with no
+        // release fence (cdna_hip_programming.md, split-K hand-off by arrival counter, the write-through form)
+        const int vo = (int)((((int64_t)item * p.hq + hq) * D + 4 * qd) * 4);
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(V4, o[db]), part_rsrc, vo + db * 64, 0, 16);
+        if (qd == 0) {
+          const float2 ml = make_float2(m, l);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.part_ml + ((int64_t)item * p.hq + hq) * 2),
+                             __builtin_bit_cast(unsigned long long, ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if constexpr (kCombine) {
+      if (!single) {
+        // arrival counter of (request, kv head): every piece adds one after its partial sums are in memory; the piece
+        // that draws nch - 1 is the last and combines all of them -- in piece order with the arithmetic of
+        // attn_decode_merge_kernel, so the result does not depend on who arrives last -- reading with sc1 loads
+        // (the producers stored write-through; this CU's L1 may hold stale lines of the workspace).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* ticket = p.arrivals + (int64_t)b * kTicketHeads + h;
+        int drawn = 0;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drawn = sgpr(drawn);
+        if (drawn == nch - 1) {
+          if (lane == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+          if (tok < G) {
+            const int hq = hq0 + tok;
+            float mx = kNegBig;
+            for (int j = 0; j < nch; ++j) {
+              const unsigned long long u = __hip_atomic_load(
+                  reinterpret_cast<unsigned long long*>(p.part_ml + ((int64_t)(first_item + j) * p.hq + hq) * 2),
+                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              mx = fmaxf(mx, __builtin_bit_cast(float2, u).x);
+            }
+            f32x4 acc[8];
+#pragma unroll
+            for (int db = 0; db < 8; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float den = 0.f;
+            for (int j = 0; j < nch; ++j) {
+              const int64_t base = (int64_t)(first_item + j) * p.hq + hq;
+              const unsigned long long u = __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.part_ml + base * 2),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const float2 ml = __builtin_bit_cast(float2, u);
+              const float wgt = __builtin_amdgcn_exp2f(ml.x - mx);
+              const int vo = (int)((base * D + 4 * qd) * 4);
+#pragma unroll
+              for (int db = 0; db < 8; ++db) {
+                const f32x4 oj = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(part_rsrc, vo + db * 64, 0, 16));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[db][i] = fmaf(wgt, oj[i], acc[db][i]);
+              }
+              den = fmaf(wgt, ml.y, den);
+            }
+            const float inv = 1.0f / den;
+            uint16_t* op = p.out + (int64_t)b * p.out_stride + (int64_t)hq * D + 4 * qd;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+              uint2 u;
+              u.x = Elem<T>::pack(acc[db][0] * inv, acc[db][1] * inv);
+              u.y = Elem<T>::pack(acc[db][2] * inv, acc[db][3] * inv);
+              *reinterpret_cast<uint2*>(op + db * 16) = u;
+            }
+          }
         }
       }
     }
@@ -888,6 +968,7 @@ static int decode_impl() {
 // products (diagnosis).
 static int mfma_variant(int G) {
   const int c = decode_impl();
+  if (c == 72) return 22;  // variant 22 with the in-kernel combine
   if (c >= 10 && c < 92) return c;
   return G <= 2 && c < 92 ? 32 : 22;
 }
@@ -896,25 +977,41 @@ template <typename T, int G>
 static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
   // same number of waves as the plan was made for (decode_target_slots): any grid >= n_slots * hv is correct
   const int64_t waves = (int64_t)decode_target_slots(G, p.hv, capacity, p.max_bs) * p.hv;
-#define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW)                                                         \
-  attn_decode_mfma_kernel<T, STAGES, WAVES, MINW>                                                     \
+  // select code 72: the last-arriving piece of a request combines the partial sums inside the kernel instead of the merge
+  // launch (needs the arrival counters to cover the kv heads and 32-bit offsets into the partial sums).  Bit-identical
+  // to the merge kernel, measured equal or slower (the combiner's three dependent sc1 round trips sit at the very end
+  // of the kernel, the merge launch they replace costs about as much: profiles/r02d_decode_attention_findings.txt),
+  // so it is not the default.
+  const bool combine = decode_impl() == 72 && p.hv <= kTicketHeads &&
+                       (int64_t)capacity * p.hq * 128 * (int64_t)sizeof(float) < (1ll << 31);
+#define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, ...)                                                    \
+  attn_decode_mfma_kernel<T, STAGES, WAVES, MINW, __VA_ARGS__>                                        \
       <<<dim3((unsigned)((waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, s>>>(p)
+#define MSGL_MFMA_VARIANT(STAGES, WAVES, MINW)                               \
+  do {                                                                       \
+    if (combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true);  \
+    else MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false);         \
+  } while (0)
   switch (decode_impl() >= 92 ? decode_impl() : mfma_variant(G)) {
-    case 22: MSGL_MFMA_LAUNCH(2, 8, 2); break;
-    case 23: MSGL_MFMA_LAUNCH(3, 8, 2); break;
-    case 32: MSGL_MFMA_LAUNCH(2, 4, 3); break;
-    case 92:
-      attn_decode_mfma_kernel<T, 2, 8, 2, true><<<dim3((unsigned)((waves + 7) / 8)), dim3(512), 0, s>>>(p);
+    case 22: MSGL_MFMA_VARIANT(2, 8, 2); break;
+    case 23: MSGL_MFMA_VARIANT(3, 8, 2); break;
+    case 32: MSGL_MFMA_VARIANT(2, 4, 3); break;
+    case 92:  // variant 22 without the products
+      if (combine) MSGL_MFMA_LAUNCH(2, 8, 2, true, false, true);
+      else MSGL_MFMA_LAUNCH(2, 8, 2, true, false, false);
       break;
     case 93:  // variant 22 with clock stamps per wave (msgl_attn_decode_trace)
-      attn_decode_mfma_kernel<T, 2, 8, 2, false, true><<<dim3((unsigned)((waves + 7) / 8)), dim3(512), 0, s>>>(p);
+      if (combine) MSGL_MFMA_LAUNCH(2, 8, 2, false, true, true);
+      else MSGL_MFMA_LAUNCH(2, 8, 2, false, true, false);
       break;
-
-    default: MSGL_MFMA_LAUNCH(4, 8, 2); break;
+    default: MSGL_MFMA_VARIANT(4, 8, 2); break;
   }
+#undef MSGL_MFMA_VARIANT
 #undef MSGL_MFMA_LAUNCH
-  const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
-  attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
+  if (!combine) {
+    const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
+    attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
+  }
   return MSGL_OK;
 }
 
@@ -954,7 +1051,7 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 92 || impl == 93,
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 72 || impl == 92 || impl == 93,
                "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
                "w waves per SIMD and s ring stages)", impl);
   g_decode_impl = impl;
@@ -968,7 +1065,7 @@ extern "C" int msgl_attn_decode_trace(void* stamps) {
 
 extern "C" int64_t msgl_attn_decode_plan_words(int max_bs, int capacity) {
   if (max_bs < 1 || capacity < max_bs) return MSGL_EINVAL;
-  return plan_off_items(max_bs, capacity) + 4ll * capacity;
+  return plan_off_arrivals(max_bs, capacity) + (int64_t)max_bs * kTicketHeads;
 }
 
 extern "C" int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim) {
@@ -1045,6 +1142,7 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
   p.slot_run = slot_run;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.trace = g_decode_trace;
+  p.arrivals = const_cast<int*>(plan) + plan_off_arrivals(max_bs, capacity);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (dtype == MSGL_BF16) rc = dispatch_group<BF16>(G, p, batch, capacity, s);

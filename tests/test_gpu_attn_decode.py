@@ -302,3 +302,66 @@ def test_decode_graph_replay(ops, dev):
         graph.replay()
         torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu().double(), oracle(case), **TOL)
+
+
+@pytest.mark.parametrize("hq,hkv,lens_kind", [(40, 8, "bench"), (16, 2, "ragged"), (64, 8, "ragged"), (8, 1, "many_pieces")])
+def test_decode_in_kernel_combine_equals_the_merge_kernel(ops, dev, hq, hkv, lens_kind):
+    """Matrix-core kernel, select code 72: the piece of a request that arrives LAST combines the partial sums inside the
+    kernel (write-through stores, arrival counter, sc1 loads).  The result must be the merge kernel's bit for bit -- pieces
+    are combined in piece order whoever arrives last -- on every launch of a sequence (the counters return to zero), and
+    under hipGraph replay."""
+    g = torch.Generator().manual_seed(hq * 7 + hkv)
+    if lens_kind == "bench":
+        lens = [int(x) for x in torch.randint(300, 2000, (96,), generator=g)]
+    elif lens_kind == "ragged":
+        lens = [1, 17, 300, 4000, 33, 2500, 64, 999, 16, 1500, 7, 3100]
+    else:
+        lens = [9000, 40, 7000, 3]
+    case = make_case(g, len(lens), hq, hkv, lens, 256)
+    ref = oracle(case)
+    ops.attn_decode_select(22)          # the same kernel with the separate merge kernel
+    want, plan = run_decode(ops, dev, case, slot_run=256, min_chunk=64)
+    n_items = int(plan[0])
+    assert n_items > len(lens), "the scenario must split requests"
+    torch.testing.assert_close(want.double(), ref, **TOL)
+    try:
+        ops.attn_decode_select(72)
+        _combine_checks(ops, dev, case, lens, hq, hkv, want)
+    finally:
+        ops.attn_decode_select(0)
+
+
+def _combine_checks(ops, dev, case, lens, hq, hkv, want):
+    for _ in range(3):
+        got, _ = run_decode(ops, dev, case, slot_run=256, min_chunk=64)
+        assert torch.equal(got, want)
+    # many launches on one plan (as the 40 layers of a step), then under graph replay
+    B, D = len(lens), 128
+    cap = max(4 * B, 1024)
+    qkv = case["qkv"].to(dev)
+    q = qkv[:, : hq * D].view(B, hq, D)
+    k, v, table = case["k"].to(dev), case["v"].to(dev), case["table"].to(dev)
+    rows = torch.tensor(case["rows"], dtype=torch.int32, device=dev)
+    seq = torch.tensor(lens, dtype=torch.int32, device=dev)
+    plan = torch.zeros(ops.attn_decode_plan_words(B, cap), dtype=torch.int32, device=dev)
+    ws = torch.empty(ops.attn_decode_workspace_bytes(cap, hq, D), dtype=torch.uint8, device=dev)
+    ops.attn_decode_plan(plan, seq, B, B, cap, hq, hkv, 64)
+    outs = [torch.empty((B, hq, D), dtype=qkv.dtype, device=dev) for _ in range(12)]
+    for o in outs:
+        ops.attn_decode(o, q, k, v, table, rows, seq, plan, ws, B, B, cap, D ** -0.5, slot_run=256)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o.cpu(), want)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            for o in outs[:4]:
+                ops.attn_decode(o, q, k, v, table, rows, seq, plan, ws, B, B, cap, D ** -0.5, slot_run=256)
+        for _ in range(3):
+            for o in outs[:4]:
+                o.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            for o in outs[:4]:
+                assert torch.equal(o.cpu(), want)
