@@ -171,7 +171,10 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
-    device = torch.device(f"cuda:{local_rank}")
+    # MSGL_BENCH_SHARE_GPU=1: every rank on cuda:0 with the peer-to-peer communicator only (RCCL refuses two ranks per
+    # device) -- exercises the whole N > 1 code path of this file on a 1-GPU box; not a measurement
+    share_gpu = os.environ.get("MSGL_BENCH_SHARE_GPU") == "1"
+    device = torch.device("cuda:0" if share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
     from mini_sglang_amd import ops
@@ -196,8 +199,12 @@ def main() -> None:
         # buffers, prefill-size ones through RCCL; a second communicator serves the side stream
         p2p_bytes = max(args.batch * PRESETS[args.model].hidden_size * 2,
                         args.batch * (-(-PRESETS[args.model].vocab_size // world)) * 2)
-        comm = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=p2p_bytes)
-        comm_side = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=p2p_bytes)
+        if share_gpu:  # every message must fit the mapped buffers: size them for a prefill chunk as well
+            p2p_bytes = max(p2p_bytes, 16384 * PRESETS[args.model].hidden_size * 2)
+        backend = "p2p" if share_gpu else "hybrid"
+        comm = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=p2p_bytes, backend=backend)
+        comm_side = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=p2p_bytes,
+                                backend=backend)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -216,6 +223,8 @@ def main() -> None:
                         cuda_graph_bs=sorted(set([b for b in small_batches if b < B] + [B])) if use_graph else [],
                         page_size=args.page_size,
                         max_seq_len_override=max_seq, comm=comm, comm_side=comm_side, memory_ratio=0.9,
+                        # ranks sharing one GPU cannot each take 90 % of its memory: a fixed pool that holds the batch
+                        num_page_override=(B * (max_seq // 2) // args.page_size) if share_gpu else None,
                         comm_split_tokens=2048 if world > 1 else 0, tp_cpu_group=dist.group.WORLD if world > 1 else None,
                         gemm_tune=os.environ.get("MSGL_GEMM_TUNE", "full"))
     engine, err = None, None
@@ -359,7 +368,8 @@ def main() -> None:
                         f"distribution (mean {S / B:.0f}), page_size {args.page_size}, temperature 0.6, hipGraph "
                         f"{'on' if use_graph else 'off'}",
             "batch": B, "parallelism": f"tp{world}", "mean_context": S / B,
-            "collectives": None if world == 1 else ("p2p (decode-size) + rccl" if comm.p2p is not None else "rccl"),
+            "collectives": None if world == 1 else ("p2p only, all ranks on ONE gpu (code-path check)" if share_gpu else
+                                                    "p2p (decode-size) + rccl" if comm.p2p is not None else "rccl"),
         },
         "ttft_p50_ms": ttft_p50,
         "small_batch_ms_per_step": small,
