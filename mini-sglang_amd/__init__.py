@@ -10,6 +10,7 @@ Layout (only what the hot path needs):
   kvcache.py         MHAKVCache mirror (P/kvcache/mha_pool.py)
   attention.py       HipAttnBackend: the BaseAttnBackend plugin (P/attention/base.py)
   radix.py           RadixPrefixCache with the tree walk in native code (P/kvcache/radix_cache.py)
+  sched_glue.py      vectorised positions / input / write index tensors (P/scheduler/scheduler.py:236-267)
   gemm_plan.py       per-shape kernel choice for the projection GEMMs, timed before graph capture
   model.py, engine.py, offline.py  dense decoder, engine and offline driver used by bench.py / smoke (callers of the path)
   minisgl_plugin.py  registers all of the above into a real `minisgl` install

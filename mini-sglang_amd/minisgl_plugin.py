@@ -320,16 +320,35 @@ def _install_native_radix(replace_radix: bool) -> None:
         reg["radix"] = reg["hip_radix"]
 
 
+# ------------------------------------------------------------------------------ vectorised scheduler glue (opt-in)
+def _install_vectorized_glue() -> None:
+    """`_make_positions`, `_make_input_tuple`, `_make_write_tuple` of P/scheduler/scheduler.py:236-267 (module-level
+    names looked up by `Scheduler._prepare_batch` at call time) -> the numpy versions of sched_glue.py."""
+    import minisgl.scheduler.scheduler as sched
+
+    from . import sched_glue
+
+    if getattr(sched._make_positions, "_msgl_vectorized", False):
+        return
+    _STATE["reference_glue"] = (sched._make_positions, sched._make_input_tuple, sched._make_write_tuple)
+    for name, fn in (("_make_positions", sched_glue.make_positions), ("_make_input_tuple", sched_glue.make_input_tuple),
+                     ("_make_write_tuple", sched_glue.make_write_tuple)):
+        fn._msgl_vectorized = True  # type: ignore[attr-defined]
+        setattr(sched, name, fn)
+
+
 def gemm_report() -> List[dict]:
     """What the last pre-capture search chose (one dict per (batch size, projection))."""
     return list(_STATE["gemm_report"])
 
 
 def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True,
-            gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False, native_radix: bool = False) -> None:
+            gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False, native_radix: bool = False,
+            vectorized_glue: bool = False) -> None:
     """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic").
     deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices).
-    native_radix: cache_type="radix" uses the native tree walk too (cache_type="hip_radix" always does)."""
+    native_radix: cache_type="radix" uses the native tree walk too (cache_type="hip_radix" always does).
+    vectorized_glue: the scheduler's per-step index tensors (positions, input / write tuples) by numpy over the whole batch."""
     if stub_zmq:
         _stub_zmq()
     _install_flashinfer_shim()
@@ -366,3 +385,5 @@ def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention:
     if deterministic_decode_order:
         _install_deterministic_decode_order()
     _install_native_radix(replace_radix=native_radix)
+    if vectorized_glue:
+        _install_vectorized_glue()

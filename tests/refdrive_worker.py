@@ -47,7 +47,8 @@ def main() -> None:
 
     plugin.install(fast_linear=spec.get("fast_linear", True), fused_attention=spec.get("fused_attention", True),
                    gemm_tune=spec.get("gemm_tune", "off"),
-                   deterministic_decode_order=spec.get("deterministic_decode_order", False))
+                   deterministic_decode_order=spec.get("deterministic_decode_order", False),
+                   vectorized_glue=spec.get("vectorized_glue", False))
     import torch
 
     from refdrive import write_model_dir

@@ -104,3 +104,73 @@ def test_install_rebinds_every_seam_of_the_reference():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(ROOT / "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "seams ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.skipif(refdrive.reference_root() is None, reason="no importable reference")
+def test_vectorized_scheduler_glue_equals_the_reference_functions():
+    """sched_glue.make_positions / make_input_tuple / make_write_tuple against `_make_positions`, `_make_input_tuple`,
+    `_make_write_tuple` of the reference (P/scheduler/scheduler.py:236-267) on random prefill, chunked and decode
+    batches incl. padded dummy requests: equal dtype, shape and values; plus the host time of both at a 256-request
+    decode batch."""
+    code = textwrap.dedent(f"""
+        import sys, time, random, types
+        sys.path.insert(0, {str(refdrive.reference_root())!r}); sys.path.insert(0, {str(ROOT)!r})
+        import torch
+        if not torch.cuda.is_available():   # pinned host memory needs a GPU runtime; the values do not depend on pinning
+            def _no_pin(fn):
+                def wrapped(*a, **k):
+                    k.pop("pin_memory", None)
+                    return fn(*a, **k)
+                return wrapped
+            torch.empty, torch.tensor = _no_pin(torch.empty), _no_pin(torch.tensor)
+        import mini_sglang_amd.minisgl_plugin as plugin
+        plugin.install(gemm_tune="off")
+        import minisgl.scheduler.scheduler as sched
+        from minisgl.core import Batch, Req, SamplingParams
+        from mini_sglang_amd import sched_glue
+        ref = (sched._make_positions, sched._make_input_tuple, sched._make_write_tuple)
+        rnd = random.Random(5)
+        dev = torch.device("cpu")
+
+        def make_batch(n, phase, pad):
+            reqs = []
+            for i in range(n):
+                dl = rnd.randint(2, 300)
+                cl = dl - 1 if phase == "decode" else rnd.randint(0, dl - 1)
+                reqs.append(Req(input_ids=torch.zeros(dl, dtype=torch.int32), table_idx=rnd.randrange(64), cached_len=cl,
+                                output_len=rnd.choice([0, 0, 3]), uid=i, sampling_params=SamplingParams(), cache_handle=None))
+            b = Batch(reqs=reqs, phase=phase)
+            dummy = Req(input_ids=torch.zeros(1, dtype=torch.int32), table_idx=64, cached_len=0, output_len=1, uid=-1,
+                        sampling_params=SamplingParams(), cache_handle=None)
+            b.padded_reqs = reqs + [dummy] * pad
+            return b
+
+        def same(a, b):
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), (a, b)
+
+        for trial in range(200):
+            b = make_batch(rnd.randint(1, 40), rnd.choice(["prefill", "decode"]), rnd.choice([0, 0, 3]))
+            b.positions = ref[0](b, dev)
+            same(b.positions, sched_glue.make_positions(b, dev))
+            for x, y in zip(ref[1](b, dev), sched_glue.make_input_tuple(b, dev)):
+                same(x, y)
+            for x, y in zip(ref[2](b, dev), sched_glue.make_write_tuple(b, dev)):
+                same(x, y)
+        # host time at a full decode batch
+        b = make_batch(256, "decode", 0)
+        def timed(fns):
+            t0 = time.perf_counter()
+            for _ in range(50):
+                b.positions = fns[0](b, dev); fns[1](b, dev); fns[2](b, dev)
+            return (time.perf_counter() - t0) / 50 * 1e6
+        t_ref, t_mine = timed(ref), timed((sched_glue.make_positions, sched_glue.make_input_tuple, sched_glue.make_write_tuple))
+        print(f"glue us per step: reference {{t_ref:.0f}} vectorised {{t_mine:.0f}}")
+        assert t_mine < t_ref
+        plugin.install(gemm_tune="off", vectorized_glue=True)
+        assert sched._make_positions is sched_glue.make_positions and sched._make_write_tuple is sched_glue.make_write_tuple
+        print("glue ok")
+    """)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=str(ROOT / "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "glue ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    print(r.stdout.strip().splitlines()[-2])

@@ -239,7 +239,7 @@ def test_reference_driven_radix_chunked_prefill_and_repeats_tiny(dev, model_dirs
 
 
 def test_reference_driven_native_radix_makes_the_same_schedule(dev, model_dirs):
-    """cache_type="hip_radix" (native tree walk, csrc/radix.cpp) under the reference's scheduler on the GPU: the same
+    """cache_type="hip_radix" (native tree walk, csrc/radix.cpp) + vectorised scheduler glue under the reference's scheduler on the GPU: the same
     prompts, greedy, produce the same batches -- cached lengths, KV block indices (out_loc, page-table rows), graph use --
     logits and tokens as with the reference's own RadixPrefixCache, and the cache ends in the same state."""
     mdir, _ = model_dirs("tiny")
@@ -248,8 +248,9 @@ def test_reference_driven_native_radix_makes_the_same_schedule(dev, model_dirs):
         kw = dict(page_size=16, max_running_req=8, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512,
                   num_page_override=256, max_extend_tokens=64, cache_type=kind)
         rounds = [dict(prompts=ps, sampling=[greedy(6)] * len(ps)) for ps in tiny_rounds()]
+        # the second run also swaps the scheduler's per-step index tensors for the numpy versions (sched_glue.py)
         recs[kind] = refdrive.run_worker(dict(model="tiny", model_dir=mdir, llm_kwargs=kw, rounds=rounds, max_position=4096,
-                                              deterministic_decode_order=True))
+                                              deterministic_decode_order=True, vectorized_glue=kind == "hip_radix"))
     a, b = recs["radix"], recs["hip_radix"]
     assert a["integrity"] == b["integrity"] == "ok" and a["outputs"] == b["outputs"]
     assert b["prefix_cache"] == "NativeRadixPrefixCache" and a["prefix_cache"] == "RadixPrefixCache"
