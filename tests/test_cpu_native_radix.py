@@ -18,7 +18,7 @@ import refdrive
 
 ROOT = Path(__file__).resolve().parent.parent
 
-pytestmark = pytest.mark.skipif(refdrive.reference_root() is None, reason="no importable reference")
+needs_reference = pytest.mark.skipif(refdrive.reference_root() is None, reason="no importable reference")
 
 
 def run(code: str, timeout: int = 600) -> str:
@@ -55,6 +55,7 @@ def run(code: str, timeout: int = 600) -> str:
     return r.stdout
 
 
+@needs_reference
 def test_native_radix_equals_reference_on_random_call_streams():
     out = run("""
         def stream(page_size, div, seed, steps):
@@ -150,6 +151,7 @@ def test_native_radix_equals_reference_on_random_call_streams():
     assert "radix parity ok" in out
 
 
+@needs_reference
 def test_cache_manager_hands_out_the_same_pages_over_either_cache():
     out = run("""
         import time, types
@@ -221,3 +223,46 @@ def test_cache_manager_hands_out_the_same_pages_over_either_cache():
         print("cache manager parity ok")
     """)
     assert "cache manager parity ok" in out
+
+
+def test_native_radix_tree_c_abi_without_the_reference():
+    """The C-ABI of the tree on its own (runs wherever libmsgl_hip.so loads, reference or not): a hand-checked scenario --
+    insert, partial match with a page-aligned split, lock / unlock sizes, LRU eviction order, stale ids, ragged keys."""
+    import torch
+
+    from mini_sglang_amd._lib import MsglError
+    from mini_sglang_amd.radix import NativeRadixTree
+
+    tick = iter(range(100, 10 ** 6))
+    t = NativeRadixTree(4, clock=lambda: next(tick))
+    ids = lambda *x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
+    assert t.walk(ids(1, 2, 3, 4, 5, 6, 7, 8)) == (0, 0, None)               # empty tree: root, nothing matched
+    a = t.add_child(0, ids(1, 2, 3, 4, 5, 6, 7, 8))                           # node a: two pages
+    assert t.info(a) == (8, 0, 2, 8)
+    # 6 equal tokens -> one whole page matches -> a is split at 4: head (new id) + tail (a keeps its id)
+    node, matched, split = t.walk(ids(1, 2, 3, 4, 5, 6, 9, 9))
+    assert matched == 4 and split == (node, a, 4) and t.info(node)[3] == 4 and t.info(a)[3] == 4
+    head = node
+    b = t.add_child(head, ids(5, 6, 9, 9))                                    # sibling of a's tail under the head
+    assert t.path(b) == [head, b] and t.path(a) == [head, a]
+    assert t.walk(ids(1, 2, 3))[:2] == (0, 0)                                 # shorter than a page: no lookup
+    t.lock(b, unlock=False)
+    assert t.info()[:2] == (4, 8)                                             # head + b protected, a's tail evictable
+    with pytest.raises(AssertionError, match="Cannot evict 8, only 4 is evictable"):
+        t.evict(8)
+    assert t.evict(1) == [a]                                                  # the only unreferenced leaf
+    with pytest.raises(MsglError, match="unknown node"):
+        t.path(a)
+    t.lock(b, unlock=True)
+    assert t.info()[:2] == (8, 0)
+    c = t.add_child(0, ids(7, 7, 7, 7))
+    t.walk(ids(1, 2, 3, 4, 5, 6, 9, 9))                                       # touches head and b: c is now the oldest
+    assert t.evict(4) == [c]
+    assert t.evict(8) == [b, head]                                            # leaf first, then its parent becomes a leaf
+    assert t.info()[:3] == (0, 0, 1)
+    with pytest.raises(MsglError, match="whole number of pages"):
+        t.add_child(0, ids(1, 2, 3))
+    with pytest.raises(MsglError, match="not locked"):
+        t.lock(t.add_child(0, ids(1, 1, 1, 1)), unlock=True)
+    t.check()
+    t.close()
