@@ -158,6 +158,7 @@ _PENDING_SLABS: dict = {}
 
 def _no_pending_slabs(device: torch.device) -> None:
     if _PENDING_SLABS and _PENDING_SLABS.get(device.index or 0) is not None:
+        _PENDING_SLABS[device.index or 0] = None  # report once: a failed forward must not poison every later GEMM
         raise RuntimeError("a split-K projection's partial sums are still waiting for fused_add_rmsnorm_slabs: "
                            "linear_slabs() output was handed to a different consumer (not fused_add_rmsnorm_slabs / "
                            "qk_norm_rope_store_slabs)")

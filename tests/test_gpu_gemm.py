@@ -286,6 +286,9 @@ def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, 
         assert slabs is not None and slabs.count == split
         with pytest.raises(RuntimeError, match="partial sums"):
             ops.linear(x, w)                    # workspace still owed to the norm
+        with pytest.raises(RuntimeError, match="no longer"):
+            ops.fused_add_rmsnorm_slabs(y, res0.clone(), nw, 1e-6, slabs)   # reported once, then the hand-off is void
+        y, slabs = ops.linear_slabs(x, w)
         y._msgl_slabs = slabs
         r = res0.clone()
         fi.fused_add_rmsnorm(y, r, nw, 1e-6)   # the shim the reference's RMSNormFused calls
