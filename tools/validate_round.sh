@@ -42,3 +42,14 @@ grep algorithmic $R/gpurun_out/${TAG}_attn_kt.log
 ALGO=$(grep algorithmic_bytes_per_launch $R/gpurun_out/${TAG}_attn_kt.log | awk '{print $2}')
 python $R/tools/pmc_json.py $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt \
   $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt $ALGO $R/gpurun_out/${TAG}_pmc_attn_decode.json "validate_round.sh $TAG" | cut -c1-400
+# same-box A/B of the decode attention kernels, per-wave clock stamps of the default one, MFMA counters of prefill attention
+cd $R
+timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,0.6b,14b_b32 --impls 1,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
+head -8 gpurun_out/${TAG}_decode_ab.txt
+timeout 200 python tools/decode_trace.py --out gpurun_out/${TAG}_decode_trace.json > /dev/null 2>&1
+cd /tmp
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/${TAG}_pmc_mfma -- python $R/tools/microbench.py --only prefill --out $R/gpurun_out/${TAG}_microbench_prefill_under_pmc.json > $R/gpurun_out/${TAG}_pmc_mfma.log 2>&1
+DB=$(find $R/gpurun_out/${TAG}_pmc_mfma -name "*results.db" | head -1)
+timeout 120 python $R/tools/rocpd_summary.py $DB --top 12 > $R/gpurun_out/${TAG}_pmc_mfma_prefill_attention.txt 2>&1
+grep -A6 "kernel,counter" $R/gpurun_out/${TAG}_pmc_mfma_prefill_attention.txt | cut -c1-160
+find $R/gpurun_out/${TAG}_pmc_mfma -name "*.db" -delete
