@@ -394,7 +394,10 @@ def main() -> None:
                         tflops=round(2.0 * r["M"] * r["N"] * r["K"] / r["best_us"] / 1e6, 1),
                         weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2),
                         **({"hand_written": r["kernel"], "library_best_us": round(r["library_best_us"], 1)}
-                           if r.get("skinny_used") else {})) for r in engine.gemm_report],
+                           if r.get("skinny_used") else {}),
+                        **({"projection_then_silu_us": round(r["silu_unfused_us"], 1),
+                            "fused_silu_epilogue_us": round(r["silu_fused_us"], 1), "fused_silu_used": r["silu_fused_used"]}
+                           if r.get("silu_fused_us") else {})) for r in engine.gemm_report],
     }
     # what the REFERENCE's own LLM / Scheduler / GraphRunner measure on this path through the plugin: recorded by
     # tests/test_gpu_reference_driven.py (it may import oracle/_ref, this file may not) and committed under profiles/

@@ -146,6 +146,13 @@ int msgl_qk_norm_rope_store_slabs(void* qkv, int64_t qkv_stride, const float* sl
 int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
                       int64_t out_stride, int dtype, void* stream);
 
+/* The same activation for a gate_up row whose columns are interleaved in blocks of 32 (gate, up, gate, up per 128
+ * columns: the weight layout msgl_g3_gemm_nt's fused epilogue needs, applied once at load time to the rows of
+ * gate_up_proj.weight): out[t, 64 c + 32 q + r] = silu(x[t, 128 c + 64 q + r]) * x[t, 128 c + 64 q + 32 + r].
+ * d % 64 == 0. */
+int msgl_silu_and_mul_interleaved(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                                  int64_t out_stride, int dtype, void* stream);
+
 /* out[t, j] = gelu(x[t, j]) * x[t, d + j], exact (erf) GELU.  Replaces flashinfer.gelu_and_mul
  * (P/layers/activation.py:15-18; chosen by hidden_act == "gelu", P/models/utils.py:37-41). */
 int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
@@ -299,6 +306,25 @@ int msgl_m256_gemm_nt(void* out, const void* x, const void* w, int M, int N, int
 int msgl_m256_gemm_slabs_nt(const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
                             int dtype, int grid, int tail_split, void* workspace, int64_t workspace_bytes,
                             void* stream);
+
+/* Generation 3 of the full-batch projection (csrc/gemm_g3.hip), same product and the same plan triple as
+ * msgl_m256_gemm_nt: four loader waves per workgroup stream both operands by LDS-DMA into a three-stage LDS ring,
+ * four matrix waves run v_mfma_f32_32x32x16 and never issue a vector-memory instruction inside the k loop.
+ * `flags`:
+ *   MSGL_G3_SILU        `w` is a gate_up matrix whose rows are interleaved in blocks of 32 (tile t of 128 rows =
+ *                       gate[64t, +32), up[64t, +32), gate[64t+32, +32), up[64t+32, +32): ops.interleave_gate_up);
+ *                       `out` is [M, N/2] = silu(gate) * up, bit-identical to rounding the projection to the 16-bit
+ *                       type and applying msgl_silu_and_mul_interleaved (P/layers/activation.py:9-12 after
+ *                       P/layers/linear.py:32).
+ *   MSGL_G3_SLABS_ONLY  pure k-slicing (full == 0, tail_split > 1) without the reduce launch: `workspace` keeps the
+ *                       fp32 slabs [tail_split][M][N] for the consumer (as msgl_m256_gemm_slabs_nt); `out` unused.
+ *   bits 8-15           diagnosis variants (cache policy of the weight stream, ablations): 0 in production.
+ * Workspace: msgl_m256_gemm_workspace_bytes(M, N, full, tail_split). */
+#define MSGL_G3_SILU 1
+#define MSGL_G3_SLABS_ONLY 2
+int msgl_g3_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                    int64_t ldo, int dtype, int grid, int full, int tail_split, int flags, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Native radix prefix tree (libmsgl_hip.so, csrc/radix.cpp; host code, no device work).

@@ -51,6 +51,7 @@ HIP_SIGNATURES = {
     ),
     "msgl_silu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_gelu_and_mul": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
+    "msgl_silu_and_mul_interleaved": (_i, [_p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_attn_decode_select": (_i, [_i]),
     "msgl_attn_decode_trace": (_i, [_p]),
     "msgl_attn_decode_plan_words": (_l, [_i, _i]),
@@ -93,6 +94,7 @@ HIP_SIGNATURES = {
     "msgl_m256_gemm_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "msgl_m256_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
     "msgl_m256_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),
+    "msgl_g3_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _i, _p, _l, _p]),
 }
 
 COMM_SIGNATURES = {

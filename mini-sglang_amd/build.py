@@ -38,6 +38,7 @@ HIP_SOURCES = [
     "gemm_skinny.hip",
     "gemm_wstream.hip",
     "gemm_m256.hip",
+    "gemm_g3.hip",
     "comm_p2p.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]

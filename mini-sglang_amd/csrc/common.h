@@ -143,6 +143,10 @@ __device__ __forceinline__ float wave_max(float x) {
   return x;
 }
 
+// silu(g) * u in fp32: the one expression shared by the activation kernels and the fused projection epilogue
+// (csrc/gemm_g3.hip) so that they agree bit for bit
+__device__ __forceinline__ float silu_mul_f32(float g, float u) { return (g / (1.0f + __expf(-g))) * u; }
+
 __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // 16-byte vector used for every wide load/store

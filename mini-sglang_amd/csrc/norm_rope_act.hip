@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void rope_kernel(uint16_t* __restrict__ q, uin
 // ------------------------------------------------------------------------------
 // out[t, j] = act(x[t, j]) * x[t, d + j];  act = silu, or (GELU) the exact erf GELU 0.5 g (1 + erf(g / sqrt 2))
 // ------------------------------------------------------------------------------
-template <typename T, bool GELU>
+// ILV: the columns of x are a gate_up row interleaved in blocks of 32 (gate, up, gate, up per 128 columns -- the layout
+// csrc/gemm_g3.hip wants for its fused epilogue): output piece j (8 columns) reads gate at 128 (j / 8) + 64 ((j % 8) / 4)
+// + 8 (j % 4) and up 32 columns further.
+template <typename T, bool GELU, bool ILV>
 __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ x, int64_t total,
                                                        int pieces, int64_t d, int64_t xs, int64_t os) {
@@ -170,12 +173,20 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
   const int64_t t = gid / pieces;
   const int64_t j = gid - t * pieces;
   float g[8], u[8], y[8];
-  unpack8<T>(ldg16(x + t * xs + j * 8), g);
-  unpack8<T>(ldg16(x + t * xs + d + j * 8), u);
+  if constexpr (ILV) {
+    const int64_t col = (j >> 3) * 128 + ((j >> 2) & 1) * 64 + (j & 3) * 8;
+    unpack8<T>(ldg16(x + t * xs + col), g);
+    unpack8<T>(ldg16(x + t * xs + col + 32), u);
+  } else {
+    unpack8<T>(ldg16(x + t * xs + j * 8), g);
+    unpack8<T>(ldg16(x + t * xs + d + j * 8), u);
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float a = GELU ? 0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)) : g[e] / (1.0f + __expf(-g[e]));
-    y[e] = a * u[e];
+    if constexpr (GELU)
+      y[e] = 0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)) * u[e];
+    else
+      y[e] = silu_mul_f32(g[e], u[e]);
   }
   stg16(out + t * os + j * 8, pack8<T>(y));
 }
@@ -417,13 +428,13 @@ extern "C" int msgl_fused_add_rmsnorm_slabs(void* x, void* residual, const void*
   return MSGL_OK;
 }
 
-template <bool GELU>
+template <bool GELU, bool ILV = false>
 static int act_and_mul(const char* what, void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
                        int64_t out_stride, int dtype, void* stream) {
   MSGL_REQUIRE(num_tokens >= 0, "%s: negative token count", what);
   if (num_tokens == 0) return MSGL_OK;
   MSGL_REQUIRE(out && x, "%s: null pointer", what);
-  MSGL_REQUIRE(d > 0 && d % 8 == 0, "%s: d %lld must be a multiple of 8", what, (long long)d);
+  MSGL_REQUIRE(d > 0 && d % (ILV ? 64 : 8) == 0, "%s: d %lld must be a multiple of %d", what, (long long)d, ILV ? 64 : 8);
   MSGL_REQUIRE(x_stride % 8 == 0 && out_stride % 8 == 0, "%s: strides must be multiples of 8", what);
   MSGL_REQUIRE(aligned16(out) && aligned16(x), "%s: pointers must be 16-byte aligned", what);
   const int pieces = (int)(d / 8);
@@ -433,7 +444,7 @@ static int act_and_mul(const char* what, void* out, const void* x, int64_t num_t
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
-    silu_mul_kernel<T, GELU><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint16_t*)out, (const uint16_t*)x, total,
+    silu_mul_kernel<T, GELU, ILV><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((uint16_t*)out, (const uint16_t*)x, total,
                                                                            pieces, d, x_stride, out_stride);
     return MSGL_OK;
   });
@@ -445,6 +456,11 @@ static int act_and_mul(const char* what, void* out, const void* x, int64_t num_t
 extern "C" int msgl_silu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
                                  int64_t out_stride, int dtype, void* stream) {
   return act_and_mul<false>("silu_and_mul", out, x, num_tokens, d, x_stride, out_stride, dtype, stream);
+}
+
+extern "C" int msgl_silu_and_mul_interleaved(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,
+                                             int64_t out_stride, int dtype, void* stream) {
+  return act_and_mul<false, true>("silu_and_mul_interleaved", out, x, num_tokens, d, x_stride, out_stride, dtype, stream);
 }
 
 extern "C" int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, int64_t x_stride,

@@ -16,7 +16,9 @@ import torch
 
 from . import ops
 
-Group = Tuple[str, Sequence[torch.Tensor], int]  # (name, same-shaped weights rotated while timing, K)
+# (name, same-shaped weights rotated while timing, K[, {"silu_interleaved": True}]): the flag marks a gate_up group whose
+# rows are in ops.interleave_gate_up order, i.e. whose consumer is ops.linear_silu (fused epilogue candidates are timed)
+Group = Tuple
 
 
 def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], mode: str, dtype: torch.dtype,
@@ -33,7 +35,9 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
     cands = {bs: ({"heuristic": -16, "full": 0}[mode] if bs == biggest else -16) for bs in batch_sizes}
     report: List[dict] = []
     for bs in batch_sizes:
-        for name, ws, k in groups:
+        for grp in groups:
+            name, ws, k = grp[0], grp[1], grp[2]
+            flags = grp[3] if len(grp) > 3 else {}
             ws = list(ws)
             x = torch.randn((bs, k), device=device, dtype=torch.float32).to(dtype)
             r = ops.gemm_tune(x, ws, max_candidates=cands[bs], iters=8)
@@ -62,7 +66,17 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r.setdefault("library_best_us", r["best_us"])
                     r["best_us"] = mr["m256_us"]
                     r["skinny_used"] = True
-                    r["kernel"] = "msgl::m256_gemm_kernel[grid %d, whole tiles %d, k-slices %d]" % tuple(mr["plan"])
+                    r["kernel"] = ("msgl::%s[grid %d, whole tiles %d, k-slices %d]"
+                                   % ((("m256_gemm_kernel", "g3_gemm_kernel")[mr["plan"][3]],) + tuple(mr["plan"][:3])))
+            if flags.get("silu_interleaved") and ops.m256_supported(bs, r["N"], r["K"]):
+                fr = ops.fused_silu_tune(x, ws)  # projection + activation as one launch vs the two just planned
+                r.update(silu_unfused_us=fr["unfused_us"], silu_fused_us=fr["fused_us"], silu_fused_plan=fr["plan"],
+                         silu_fused_used=fr["used"], silu_fused_all=fr.get("all"))
+                if fr["used"]:
+                    r.setdefault("library_best_us", r["best_us"])
+                    r["best_us"] = fr["fused_us"]  # projection AND activation
+                    r["skinny_used"] = True
+                    r["kernel"] = "msgl::g3_gemm_kernel<silu>[grid %d, whole tiles %d, k-slices %d]" % tuple(fr["plan"])
             report.append(r)
             if log is not None:
                 log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "

@@ -155,6 +155,91 @@ def _install_fused_attention() -> None:
     _STATE["fused_attention"] = True
 
 
+# ------------------------------------------------------------------------------ fused gate_up projection + SiLU.mul
+def _install_fused_gated_mlp() -> None:
+    """`GatedMLP.forward` (P/models/utils.py:45-51) = gate_up_proj (F.linear, P/layers/linear.py:32) -> act_fn
+    (flashinfer.silu_and_mul, P/layers/activation.py:9-12) -> down_proj.  For layers whose gate_up weight
+    `_interleave_gated_mlps` has put into the block-32 interleaved row order, the first two run as
+    ops.linear_silu: one launch of csrc/gemm_g3.hip with the activation in its epilogue where the pre-capture search
+    planned it, else the projection followed by the interleaved activation kernel.  Every other layer: unchanged."""
+    from minisgl.models.utils import GatedMLP
+
+    from . import ops
+
+    if getattr(GatedMLP.forward, "_msgl_fused", False):
+        return
+    reference_forward = GatedMLP.forward
+
+    def forward(self, x):
+        if getattr(self, "_msgl_gate_up_ilv", False) and x.is_cuda and x.dim() == 2 and x.stride(1) == 1:
+            return self.down_proj.forward(ops.linear_silu(x, self.gate_up_proj.weight))
+        return reference_forward(self, x)
+
+    forward._msgl_fused = True  # type: ignore[attr-defined]
+    forward._msgl_reference = reference_forward  # type: ignore[attr-defined]
+    GatedMLP.forward = forward
+    _STATE["fused_gated_mlp"] = True
+
+
+def _interleave_gated_mlps(model: Any) -> int:
+    """Once per model, after its weights are loaded and before its first forward (GraphRunner.__init__ ->
+    _capture_graphs, P/engine/graph.py:77-100, runs exactly there): permute the rows of every SiLU GatedMLP's
+    gate_up_proj.weight ([gate shard; up shard], P/layers/linear.py:50-62) in place into ops.interleave_gate_up order
+    and mark the layer.  Returns the number of layers converted."""
+    import torch
+
+    from minisgl.layers.base import BaseOP
+    from minisgl.layers.linear import LinearColParallelMerged
+    from minisgl.models.utils import GatedMLP
+
+    from . import ops
+
+    done = 0
+
+    def walk(op: Any) -> None:
+        nonlocal done
+        if type(op) is GatedMLP:
+            gu = getattr(op, "gate_up_proj", None)
+            act = getattr(getattr(op, "act_fn", None), "__name__", "")
+            if (type(gu) is LinearColParallelMerged and gu.bias is None and act == "silu_and_mul" and gu.weight.is_cuda
+                    and gu.weight.dim() == 2 and (gu.weight.shape[0] // 2) % 64 == 0 and gu.weight.is_contiguous()
+                    and gu.weight.dtype in (torch.bfloat16, torch.float16)
+                    and not getattr(op, "_msgl_gate_up_ilv", False)):
+                w = gu.weight.data if hasattr(gu.weight, "data") else gu.weight
+                w.copy_(ops.interleave_gate_up(w))
+                op._msgl_gate_up_ilv = True
+                done += 1
+            return
+        if isinstance(op, BaseOP):
+            for sub in vars(op).values():
+                for s_ in (sub if isinstance(sub, (list, tuple)) else (sub,)):
+                    if isinstance(s_, BaseOP):
+                        walk(s_)
+
+    walk(model)
+    return done
+
+
+def _gate_up_is_interleaved(model: Any) -> set:
+    """data_ptr of the gate_up weights that are in interleaved order (their tuning group times the fused launch)."""
+    from minisgl.layers.base import BaseOP
+
+    ptrs: set = set()
+
+    def walk(op: Any) -> None:
+        if getattr(op, "_msgl_gate_up_ilv", False):
+            ptrs.add(op.gate_up_proj.weight.data_ptr())
+            return
+        if isinstance(op, BaseOP):
+            for sub in vars(op).values():
+                for s_ in (sub if isinstance(sub, (list, tuple)) else (sub,)):
+                    if isinstance(s_, BaseOP):
+                        walk(s_)
+
+    walk(model)
+    return ptrs
+
+
 # ------------------------------------------------------------------------------ GEMM plans before capture
 def _projection_groups(model: Any, require_device: bool = True) -> List[tuple]:
     """(name, same-shaped weights of up to 8 layers, K) for every distinct linear shape in the reference's op tree
@@ -253,12 +338,16 @@ def _install_tune_before_capture() -> None:
 
     def _capture_graphs(self, max_seq_len, vocab_size, model):
         mode = _STATE["gemm_tune"]
+        if _STATE.get("fused_gated_mlp") and os.environ.get("MSGL_DISABLE_FUSED_SILU") != "1":
+            _STATE["interleaved_mlps"] = _interleave_gated_mlps(model)
         if mode != "off" and self.max_graph_bs > 0 and _STATE["fast_linear"]:
             import torch
 
             from .gemm_plan import tune_projection_gemms
 
             groups = _projection_groups(model)
+            ilv = _gate_up_is_interleaved(model)
+            groups = [g + ({"silu_interleaved": True},) if all(w.data_ptr() in ilv for w in g[1]) else g for g in groups]
             if groups:
                 dtype = groups[0][1][0].dtype
                 log = (lambda m: print(m, file=sys.stderr)) if os.environ.get("MSGL_PLUGIN_VERBOSE") else None
@@ -342,10 +431,11 @@ def gemm_report() -> List[dict]:
     return list(_STATE["gemm_report"])
 
 
-def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True,
+def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True, fused_mlp: bool = True,
             gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False, native_radix: bool = False,
             vectorized_glue: bool = False) -> None:
     """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic").
+    fused_mlp: gate_up_proj + silu_and_mul of the dense GatedMLP as ops.linear_silu (weights interleaved once, in place).
     deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices).
     native_radix: cache_type="radix" uses the native tree walk too (cache_type="hip_radix" always does).
     vectorized_glue: the scheduler's per-step index tensors (positions, input / write tuples) by numpy over the whole batch."""
@@ -382,6 +472,8 @@ def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention:
         _install_tune_before_capture()
     if fused_attention:
         _install_fused_attention()
+    if fused_mlp and fast_linear:
+        _install_fused_gated_mlp()
     if deterministic_decode_order:
         _install_deterministic_decode_order()
     _install_native_radix(replace_radix=native_radix)

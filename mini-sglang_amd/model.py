@@ -28,6 +28,7 @@ from .kvcache import div_even
 
 # MSGL_DISABLE_SLAB_NORM=1: keep the split-K reduce of o_proj / down_proj as its own launch (A/B switch)
 _SLAB_NORM = os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1"
+_FUSE_SILU = os.environ.get("MSGL_DISABLE_FUSED_SILU") != "1"
 
 
 @dataclass(frozen=True)
@@ -74,7 +75,8 @@ class LayerWeights:
     k_norm: Optional[torch.Tensor]
     o: torch.Tensor         # [hidden, Hq_l * D]               row-parallel
     post_norm: torch.Tensor
-    gate_up: torch.Tensor   # [2 * I_l, hidden]                (P/layers/linear.py:56-71)
+    gate_up: torch.Tensor   # [2 * I_l, hidden]                (P/layers/linear.py:56-71); rows in
+                            # ops.interleave_gate_up order when DenseDecoder.gate_up_ilv
     down: torch.Tensor      # [hidden, I_l]                    row-parallel
 
 
@@ -155,6 +157,13 @@ class DenseDecoder:
                 input_norm=ones(H), qkv=w(self.q_dim + 2 * self.kv_dim, H),
                 q_norm=ones(D) if cfg.qk_norm else None, k_norm=ones(D) if cfg.qk_norm else None,
                 o=w(H, self.q_dim), post_norm=ones(H), gate_up=w(2 * self.inter, H), down=w(H, self.inter)))
+        # gate_up rows in the block-32 interleaved order the fused projection + SiLU.mul epilogue needs (csrc/gemm_g3.hip);
+        # every consumer goes through ops.linear_silu, the oracle gets the reference layout back (gate_up_reference)
+        self.gate_up_ilv = bool(fused and _FUSE_SILU and device.type == "cuda" and self.inter % 64 == 0)
+        if self.gate_up_ilv:
+            idx = ops.gate_up_interleave_index(self.inter, device)
+            for lw in self.layers:
+                lw.gate_up = lw.gate_up.index_select(0, idx)
         self.final_norm = ones(H)
         self.lm_head = self.embed if cfg.tie_word_embeddings else w(self.vocab_tp, H)
         self.cos_sin = fi.build_cos_sin_cache(D, cfg.max_position, cfg.rope_base, cfg.rope_scaling, device=device)
@@ -210,9 +219,20 @@ class DenseDecoder:
                 put(lw.q_norm, state[p + "self_attn.q_norm.weight"])
                 put(lw.k_norm, state[p + "self_attn.k_norm.weight"])
             put(lw.o, state[p + "self_attn.o_proj.weight"].chunk(n, dim=1)[r])
-            put(lw.gate_up, torch.cat([col(state[p + "mlp.gate_proj.weight"]), col(state[p + "mlp.up_proj.weight"])],
-                                      dim=0))
+            gu = torch.cat([col(state[p + "mlp.gate_proj.weight"]), col(state[p + "mlp.up_proj.weight"])], dim=0)
+            put(lw.gate_up, gu.index_select(0, ops.gate_up_interleave_index(self.inter, gu.device)) if self.gate_up_ilv
+                else gu)
             put(lw.down, state[p + "mlp.down_proj.weight"].chunk(n, dim=1)[r])
+
+    def gate_up_reference(self, layer: int) -> torch.Tensor:
+        """Layer `layer`'s gate_up weight in the reference's row order [gate; up] (P/layers/linear.py:56-71)."""
+        w = self.layers[layer].gate_up
+        if not self.gate_up_ilv:
+            return w
+        idx = ops.gate_up_interleave_index(self.inter, w.device)
+        inv = torch.empty_like(idx)
+        inv[idx] = torch.arange(idx.numel(), device=w.device)
+        return w.index_select(0, inv)
 
     # ------------------------------------------------------------------ GEMM solution search
     def projection_groups(self):
@@ -220,7 +240,7 @@ class DenseDecoder:
         step = max(1, len(self.layers) // 8)
         pick = self.layers[::step][:8]
         return [("qkv", [l.qkv for l in pick], self.cfg.hidden_size), ("o", [l.o for l in pick], self.q_dim),
-                ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size),
+                ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size, {"silu_interleaved": self.gate_up_ilv}),
                 ("down", [l.down for l in pick], self.inter), ("lm_head", [self.lm_head], self.cfg.hidden_size)]
 
     def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None) -> List[dict]:
@@ -302,8 +322,10 @@ class DenseDecoder:
                 o = backend.forward(q.view(-1, self.hq, D), k, v, li, batch)
             x = self.row_parallel(o.view(-1, self.q_dim), lw.o)
             fi.fused_add_rmsnorm(x, residual, lw.post_norm, cfg.rms_norm_eps)
-            gate_up = ops.linear(x, lw.gate_up)
-            y = fi.silu_and_mul(gate_up)
+            if self.gate_up_ilv:  # projection + SiLU.mul: one launch where planned (P/models/utils.py:45-51)
+                y = ops.linear_silu(x, lw.gate_up)
+            else:
+                y = fi.silu_and_mul(ops.linear(x, lw.gate_up))
             x = self.row_parallel(y, lw.down)
         fi.fused_add_rmsnorm(x, residual, self.final_norm, cfg.rms_norm_eps)
         # LM head (P/layers/embedding.py:88-110)

@@ -7,6 +7,7 @@ function does (e.g. `indexing` output), none synchronises.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -262,6 +263,28 @@ def _act_and_mul(name: str, x: torch.Tensor, out: Optional[torch.Tensor]) -> tor
 
 def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return _act_and_mul("silu_and_mul", x, out)
+
+
+def silu_and_mul_interleaved(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """silu_and_mul for a gate_up row whose columns are in the block-32 interleaved order of `interleave_gate_up`."""
+    assert (x.shape[1] // 2) % 64 == 0
+    return _act_and_mul("silu_and_mul_interleaved", x, out)
+
+
+def gate_up_interleave_index(inter: int, device=None) -> torch.Tensor:
+    """Row permutation that turns [gate (inter rows); up (inter rows)] (P/layers/linear.py:50-62, LinearColParallelMerged)
+    into the layout the fused projection epilogue wants: per 128 rows gate[64t, +32), up[64t, +32), gate[64t+32, +32),
+    up[64t+32, +32).  new_rows = old_rows[index]."""
+    assert inter % 64 == 0, inter
+    r = torch.arange(2 * inter, device=device)
+    t, q, u, j = r // 128, (r % 128) // 64, (r % 64) // 32, r % 32
+    return u * inter + 64 * t + 32 * q + j
+
+
+def interleave_gate_up(w: torch.Tensor) -> torch.Tensor:
+    """A gate_up weight [2 * inter, K] (or an activation's last dimension when w.dim() == 2 and rows are tokens: use
+    .t()) with its rows in the interleaved order (a new tensor)."""
+    return w.index_select(0, gate_up_interleave_index(w.shape[0] // 2, w.device))
 
 
 def gelu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -595,7 +618,8 @@ def wstream_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) 
 
 
 # ---- full decode batches: one workgroup per CU, LDS-DMA ring, 32x32x16 MFMA (csrc/gemm_m256.hip)
-_M256_PLAN: dict = {}  # (device, M, N, K, ldx, ldw, dtype code) -> (grid, full, tail_split)
+_M256_PLAN: dict = {}  # (device, M, N, K, ldx, ldw, dtype code) -> (grid, full, tail_split, impl); impl 0 = gemm_m256.hip, 1 = gemm_g3.hip
+_FUSED_SILU_PLAN: dict = {}  # same key (w = interleaved gate_up) -> (grid, full, tail_split) of the fused g3 launch
 M256_MIN_M, M256_MAX_M = 129, 256
 
 
@@ -644,9 +668,32 @@ def m256_candidates(M: int, N: int, K: int, cus: int):
     return out
 
 
+def _time_launches_us(fn, weights, iters: int, rounds: int) -> float:
+    """min over `rounds` of the mean time of `iters` launches of fn(w) on rotating weights (events on this stream)."""
+    fn(weights[0])  # warm-up
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            fn(weights[(i + 1) % len(weights)])
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / iters)
+    return min(ts)
+
+
+def full_batch_linear(x: torch.Tensor, w: torch.Tensor, plan, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The planned full-batch kernel: plan = (grid, full, tail_split, impl)."""
+    if len(plan) > 3 and plan[3] == 1:
+        return g3_linear(x, w, plan[0], plan[1], plan[2], out)
+    return m256_linear(x, w, plan[0], plan[1], plan[2], out)
+
+
 def m256_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) -> dict:
-    """Time the plans of m256_candidates on rotating weights and keep the fastest for this shape if it beats
-    `incumbent_us` (the best of the library and the other hand-written kernels) by PLAN_MARGIN."""
+    """Time the plans of m256_candidates with both full-batch kernels (register-staged gemm_m256.hip, loader / matrix
+    wave gemm_g3.hip) on rotating weights and keep the fastest for this shape if it beats `incumbent_us` (the best of
+    the library and the other hand-written kernels) by PLAN_MARGIN."""
     weights = list(weights)
     w0 = weights[0]
     M, K = x.shape
@@ -656,23 +703,10 @@ def m256_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) -> 
         return res
     cus = int(lib().msgl_device_cu_count())
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-
-    def time_us(plan, rounds):
-        m256_linear(x, w0, *plan, out=out)  # warm-up
-        ts = []
-        for _ in range(rounds):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(iters):
-                m256_linear(x, weights[(i + 1) % len(weights)], *plan, out=out)
-            e1.record()
-            e1.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e3 / iters)
-        return min(ts)
-
-    cands = m256_candidates(M, N, K, cus)
-    ranked = sorted((time_us(p, 1), p) for p in cands)
-    best = min((time_us(p, 3), p) for _, p in ranked[:3])
+    impls = (0, 1) if os.environ.get("MSGL_DISABLE_G3") != "1" else (0,)
+    cands = [p + (impl,) for p in m256_candidates(M, N, K, cus) for impl in impls]
+    ranked = sorted((_time_launches_us(lambda w: full_batch_linear(x, w, p, out), weights, iters, 1), p) for p in cands)
+    best = min((_time_launches_us(lambda w: full_batch_linear(x, w, p, out), weights, iters, 3), p) for _, p in ranked[:4])
     res.update(m256_us=best[0], plan=best[1], all={"/".join(map(str, p)): round(t, 1) for t, p in ranked})
     key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
     if best[0] < PLAN_MARGIN * incumbent_us:
@@ -681,6 +715,74 @@ def m256_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) -> 
     else:
         _M256_PLAN.pop(key, None)
     return res
+
+
+def fused_silu_tune(x: torch.Tensor, weights, iters: int = 8) -> dict:
+    """gate_up in interleave_gate_up order: time `linear` (whatever plan the search above left for the shape) followed
+    by silu_and_mul_interleaved against the fused-epilogue launches of gemm_g3.hip, plan the fused one if faster."""
+    weights = list(weights)
+    w0 = weights[0]
+    M, K = x.shape
+    N = w0.shape[0]
+    res = dict(M=M, N=N, K=K, unfused_us=None, fused_us=None, plan=None, used=False)
+    key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    _FUSED_SILU_PLAN.pop(key, None)
+    if not (m256_supported(M, N, K) and (N // 2) % 64 == 0) or os.environ.get("MSGL_DISABLE_G3") == "1":
+        return res
+    cus = int(lib().msgl_device_cu_count())
+    half = torch.empty((M, N // 2), dtype=x.dtype, device=x.device)
+    res["unfused_us"] = _time_launches_us(lambda w: silu_and_mul_interleaved(linear(x, w), half), weights, iters, 3)
+    ranked = sorted((_time_launches_us(lambda w: g3_linear(x, w, *p, out=half, silu=True), weights, iters, 1), p)
+                    for p in m256_candidates(M, N, K, cus))
+    best = min((_time_launches_us(lambda w: g3_linear(x, w, *p, out=half, silu=True), weights, iters, 3), p)
+               for _, p in ranked[:3])
+    res.update(fused_us=best[0], plan=best[1], all={"/".join(map(str, p)): round(t, 1) for t, p in ranked})
+    # MSGL_FORCE_FUSED_SILU=1 / =0: A/B switch (inside a captured step the two rank differently than back to back)
+    force = os.environ.get("MSGL_FORCE_FUSED_SILU")
+    if force != "0" and (force == "1" or best[0] < PLAN_MARGIN * res["unfused_us"]):
+        _FUSED_SILU_PLAN[key] = best[1]
+        res["used"] = True
+    return res
+
+
+def linear_silu(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """silu(x @ gate^T) * (x @ up^T) for a gate_up weight in interleave_gate_up order (P/models/utils.py:45-51:
+    gate_up_proj then act_fn): one fused launch where fused_silu_tune planned it, else linear + the activation kernel."""
+    M, K = x.shape
+    N = w.shape[0]
+    if M >= M256_MIN_M and _FUSED_SILU_PLAN:
+        plan = _FUSED_SILU_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return g3_linear(x, w, plan[0], plan[1], plan[2], out, silu=True)
+    return silu_and_mul_interleaved(linear(x, w), out)
+
+
+# ---- generation 3 of the full-batch kernel: loader waves + matrix waves (csrc/gemm_g3.hip); same plan triples
+G3_SILU, G3_SLABS_ONLY = 1, 2
+
+
+def g3_linear(x: torch.Tensor, w: torch.Tensor, grid: int, full: int, tail_split: int,
+              out: Optional[torch.Tensor] = None, silu: bool = False, variant: int = 0) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_g3_gemm_nt with the plan (grid, full, tail_split).  silu=True: `w` is a
+    gate_up weight in interleave_gate_up order and out[M, N/2] = silu(gate) * up."""
+    _need_cuda(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.dtype == w.dtype
+    assert x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    cols = N // 2 if silu else N
+    if out is None:
+        out = torch.empty((M, cols), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, cols) and out.stride(1) == 1 and out.dtype == x.dtype
+    _no_pending_slabs(x.device)
+    ws = gemm_workspace(x.device)
+    check(
+        lib().msgl_g3_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                              out.stride(0), _dt(x), grid, full, tail_split, (G3_SILU if silu else 0) | (variant << 8),
+                              ws.data_ptr(), ws.numel(), _stream()),
+        "g3_gemm_nt",
+    )
+    return out
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -694,7 +796,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     if M >= M256_MIN_M and _M256_PLAN:
         plan = _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
-            return m256_linear(x, w, plan[0], plan[1], plan[2], out)
+            return full_batch_linear(x, w, plan, out)
     if M <= WSTREAM_MAX_M and _WSTREAM_PLAN:
         plan = _WSTREAM_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
@@ -722,11 +824,18 @@ def linear_slabs(x: torch.Tensor, w: torch.Tensor):
         plan = _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan and plan[1] == 0 and plan[2] > 1:
             ws = gemm_workspace(x.device)
-            check(
-                lib().msgl_m256_gemm_slabs_nt(x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), _dt(x),
-                                              plan[0], plan[2], ws.data_ptr(), ws.numel(), _stream()),
-                "m256_gemm_slabs_nt",
-            )
+            if len(plan) > 3 and plan[3] == 1:
+                check(
+                    lib().msgl_g3_gemm_nt(None, x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), N, _dt(x),
+                                          plan[0], 0, plan[2], G3_SLABS_ONLY, ws.data_ptr(), ws.numel(), _stream()),
+                    "g3_gemm_nt(slabs)",
+                )
+            else:
+                check(
+                    lib().msgl_m256_gemm_slabs_nt(x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), _dt(x),
+                                                  plan[0], plan[2], ws.data_ptr(), ws.numel(), _stream()),
+                    "m256_gemm_slabs_nt",
+                )
             slabs = Slabs(ws.data_ptr(), plan[2], M, N, x.device.index or 0)
             _PENDING_SLABS[slabs.device] = slabs
             return out, slabs
@@ -740,6 +849,7 @@ def reset_gemm_plans() -> None:
     _SKINNY_PLAN.clear()
     _WSTREAM_PLAN.clear()
     _M256_PLAN.clear()
+    _FUSED_SILU_PLAN.clear()
     _PENDING_SLABS.clear()
     _lib.check_gemm(_lib.gemm_lib().msgl_gemm_reset_plans(), "gemm_reset_plans")
 

@@ -27,9 +27,11 @@ class CpuWeights:
 def weights_from_device_model(model: Any) -> CpuWeights:
     """Copy a DenseDecoder's tensors to the host (the oracle must see the same bits)."""
     layers = []
-    for lw in model.layers:
+    for li, lw in enumerate(model.layers):
         layers.append({k: (None if getattr(lw, k) is None else getattr(lw, k).detach().cpu())
                        for k in ("input_norm", "qkv", "q_norm", "k_norm", "o", "post_norm", "gate_up", "down")})
+        if getattr(model, "gate_up_ilv", False):  # the device model keeps gate_up rows interleaved for its fused epilogue
+            layers[-1]["gate_up"] = model.gate_up_reference(li).detach().cpu()
     return CpuWeights(model.embed.cpu(), layers, model.final_norm.cpu(), model.lm_head.cpu(), model.cos_sin.cpu())
 
 

@@ -246,7 +246,8 @@ def test_m256_gemm_fp16_strided_operands_and_dispatch(ops, dev):
     rep = ops.m256_tune(xb, [wb], incumbent_us=1e9)
     assert rep["used"] and rep["plan"] is not None
     _check(ops.linear(xb, wb), _ref(xb, wb))
-    assert torch.equal(ops.linear(xb, wb), ops.m256_linear(xb, wb, *rep["plan"]))
+    assert len(rep["plan"]) == 4 and rep["plan"][3] in (0, 1)
+    assert torch.equal(ops.linear(xb, wb), ops.full_batch_linear(xb, wb, rep["plan"]))
     ops._M256_PLAN.clear()
 
 
@@ -263,9 +264,97 @@ def test_m256_gemm_rejects_what_it_cannot_do(ops, dev):
         ops.m256_linear(torch.zeros((257, 256), dtype=torch.bfloat16, device=dev), w, 256, 2, 1)
 
 
+# ---------------------------------------------------------------- generation 3: loader waves + matrix waves (csrc/gemm_g3.hip)
+@pytest.mark.parametrize("M", [129, 200, 256])
+@pytest.mark.parametrize("N,K", [(5120, 5120), (7168, 5120), (128, 64), (1024, 17408), (2304, 640), (34816, 1024)])
+def test_g3_gemm_matches_fp32_reference_and_the_register_staged_kernel(ops, dev, M, N, K):
+    """Same plans as the m256 test.  The two kernels add the same 16-k MFMA blocks in the same order into the same
+    accumulator layout, so they must agree bit for bit; repeatable; padded rows (M < 256) never stored."""
+    g = torch.Generator(device=dev).manual_seed(M * 31 + N + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    ref = _ref(x, w)
+    tiles, nsteps = N // 128, K // 64
+    plans = set(ops.m256_candidates(M, N, K, 256))
+    plans |= {(8, tiles, 1), (8, 0, min(3, nsteps)), (256, tiles // 2, min(2, nsteps)), (3, max(tiles - 1, 0), min(5, nsteps)),
+              (1, tiles, 1), (300, 0, min(7, nsteps))}
+    plans = {p for p in plans if p[2] == 1 or p[2] * M * (tiles - p[1]) * 128 * 4 <= ops.GEMM_WORKSPACE_BYTES}
+    for grid, full, split in sorted(plans):
+        out = torch.full((M + 3, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.g3_linear(x, w, grid, full, split, out=out[:M])
+        _check(out[:M], ref)
+        assert bool(out[M:].isnan().all()), (grid, full, split)
+        assert torch.equal(out[:M], ops.g3_linear(x, w, grid, full, split)), (grid, full, split)
+        assert torch.equal(out[:M], ops.m256_linear(x, w, grid, full, split)), (grid, full, split)
+
+
+def test_g3_gemm_identity_fp16_strided_operands(ops, dev):
+    M, N, K = 256, 256, 256
+    x = torch.eye(K, dtype=torch.bfloat16, device=dev)[:M]
+    w = (torch.arange(N, device=dev)[:, None] * 0.25 + torch.arange(K, device=dev)[None, :] * 3.0).to(torch.bfloat16)
+    for plan in ((256, 2, 1), (256, 0, 2), (4, 1, 4)):
+        assert torch.equal(ops.g3_linear(x, w, *plan).float(), w.float().t()[:M].contiguous()), plan
+    g = torch.Generator(device=dev).manual_seed(11)
+    big = (torch.randn((200, 3 * 512), generator=g, device=dev) * 0.5).to(torch.float16)
+    xs = big[:, 512:1024]
+    ws = (torch.randn((768, 1024), generator=g, device=dev) * 0.05).to(torch.float16)[:, :512]
+    fused = torch.zeros((200, 2048), dtype=torch.float16, device=dev)
+    for plan in ((256, 6, 1), (256, 0, 4), (16, 4, 2)):
+        _check(ops.g3_linear(xs, ws, *plan, out=fused[:, 256:1024]), _ref(xs, ws))
+    assert fused[:, :256].abs().max().item() == 0 and fused[:, 1024:].abs().max().item() == 0
+    with pytest.raises(RuntimeError):
+        ops.g3_linear(x, torch.zeros((192, 256), dtype=torch.bfloat16, device=dev), 256, 1, 1)  # N % 128
+    with pytest.raises(RuntimeError):
+        ops.g3_linear(x, w, 256, 3, 1)      # more whole tiles than tiles
+    with pytest.raises(RuntimeError):
+        ops.g3_linear(torch.zeros((257, 256), dtype=torch.bfloat16, device=dev), w, 256, 2, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,inter,K,plan", [(256, 17408, 5120, (256, 256, 16)), (256, 1024, 512, (256, 16, 1)),
+                                           (200, 3072, 1024, (256, 0, 4)), (129, 512, 640, (5, 3, 2)), (256, 64, 64, (256, 1, 1))])
+def test_g3_fused_silu_equals_projection_then_activation(ops, dev, dtype, M, inter, K, plan):
+    """gate_up_proj + silu_and_mul (P/models/utils.py:45-51, P/layers/activation.py:9-12) as ONE launch on the
+    interleaved weight: bit-identical to the projection rounded to 16 bits followed by the activation kernel, which is
+    itself the reference-layout result up to the summation order of the k-sliced tail tiles; against the fp32 oracle
+    within the activation's 1-ulp-of-output bound on top of the projection's."""
+    from oracle import ref_ops
+
+    g = torch.Generator(device=dev).manual_seed(M + inter + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(dtype)
+    w = (torch.randn((2 * inter, K), generator=g, device=dev) * 0.05).to(dtype)
+    wi = ops.interleave_gate_up(w)
+    idx = ops.gate_up_interleave_index(inter, dev)
+    assert torch.equal(torch.sort(idx).values, torch.arange(2 * inter, device=dev))
+    fused = torch.full((M + 1, inter), float("nan"), dtype=dtype, device=dev)
+    ops.g3_linear(x, wi, *plan, out=fused[:M], silu=True)
+    assert bool(fused[M:].isnan().all())
+    gu = ops.g3_linear(x, wi, *plan)
+    assert torch.equal(gu, ops.g3_linear(x, w, *plan).index_select(1, idx)) or plan[2] > 1
+    assert torch.equal(fused[:M], ops.silu_and_mul_interleaved(gu))
+    # interleaved activation kernel == reference-layout activation kernel on the de-interleaved row
+    inv = torch.empty_like(idx)
+    inv[idx] = torch.arange(2 * inter, device=dev)
+    assert torch.equal(ops.silu_and_mul_interleaved(gu), ops.silu_and_mul(gu.index_select(1, inv).contiguous()))
+    want = ref_ops.silu_and_mul_ref(_ref(x, w).to(dtype).cpu()).float().to(dev)
+    err = (fused[:M].float() - want).abs()
+    assert err.max().item() <= 2 ** -6 * max(want.abs().max().item(), 1e-3), err.max().item()
+    # dispatch: linear_silu uses the plan when there is one, else projection + activation
+    key = (dev.index or 0, M, 2 * inter, K, x.stride(0), wi.stride(0), ops._dt(x))
+    try:
+        unplanned = ops.linear_silu(x, wi)
+        ops._FUSED_SILU_PLAN[key] = plan
+        planned = ops.linear_silu(x, wi)
+        assert torch.equal(planned, fused[:M])
+        assert (planned.float() - unplanned.float()).abs().max().item() <= 2 ** -6 * max(want.abs().max().item(), 1e-3)
+    finally:
+        ops._FUSED_SILU_PLAN.clear()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,split", [(256, 5120, 5120, 6), (256, 5120, 17408, 13), (130, 1024, 3072, 4), (256, 640, 640, 10)])
-def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, split):
+@pytest.mark.parametrize("impl", [0, 1])
+def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, split, impl):
     """o_proj / down_proj -> fused_add_rmsnorm with the projection's slab reduce done by the norm kernel: x and residual
     bit-identical to reduce-then-norm, the output tensor is the one linear_slabs returned, and a deferred output that
     reaches any other GEMM fails loudly instead of reading unreduced memory."""
@@ -277,7 +366,7 @@ def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, 
     res0 = torch.randn((M, N), generator=g, device=dev).to(dtype)
     nw = (1 + 0.1 * torch.randn(N, generator=g, device=dev)).to(dtype)
     key = (dev.index or 0, M, N, K, x.stride(0), w.stride(0), ops._dt(x))
-    ops._M256_PLAN[key] = (256, 0, split)
+    ops._M256_PLAN[key] = (256, 0, split, impl)
     try:
         y_ref, r_ref = ops.linear(x, w), res0.clone()
         assert torch.equal(y_ref, ops.m256_linear(x, w, 256, 0, split))
@@ -307,7 +396,8 @@ def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,hq,hk,D,K,split,qk_norm", [(256, 40, 8, 128, 5120, 4, True), (160, 16, 8, 128, 1024, 4, True),
                                                      (130, 8, 2, 64, 512, 2, False)])
-def test_split_k_reduce_folded_into_qk_norm_rope_store(ops, dev, dtype, M, hq, hk, D, K, split, qk_norm):
+@pytest.mark.parametrize("impl", [0, 1])
+def test_split_k_reduce_folded_into_qk_norm_rope_store(ops, dev, dtype, M, hq, hk, D, K, split, qk_norm, impl):
     """qkv_proj -> (q-norm, k-norm, RoPE, KV store) with the projection's slab reduce done by the fused pass: the whole
     qkv buffer (q, k AND v) and both pools bit-identical to reduce-then-qk_norm_rope_store."""
     g = torch.Generator(device=dev).manual_seed(M + hq + K)
@@ -322,7 +412,7 @@ def test_split_k_reduce_folded_into_qk_norm_rope_store(ops, dev, dtype, M, hq, h
     cos_sin = torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
     loc = torch.randperm(1024, generator=g, device=dev)[:M].to(torch.int32)
     key = (dev.index or 0, M, N, K, x.stride(0), w.stride(0), ops._dt(x))
-    ops._M256_PLAN[key] = (256, 0, split)
+    ops._M256_PLAN[key] = (256, 0, split, impl)
     try:
         qkv_ref = ops.linear(x, w)
         kc_ref, vc_ref = (torch.zeros((1024, hk * D), dtype=dtype, device=dev) for _ in range(2))
