@@ -375,7 +375,15 @@ int msgl_p2p_open(msgl_p2p_t comm, const void* all_handles /* world_size x MSGL_
 int msgl_p2p_configure(msgl_p2p_t comm, size_t one_shot_max_bytes, int blocks);
 int msgl_p2p_all_reduce_sum(msgl_p2p_t comm, void* data, size_t count, int dtype, void* stream);
 int msgl_p2p_all_gather(msgl_p2p_t comm, void* dst, const void* src, size_t count, int dtype, void* stream);
+/* A barrier that gives up (a peer did not arrive within the spin limit) sets a sticky error word (1 + phase) and the
+ * kernel POISONS its output with NaN bit patterns instead of returning a partial sum; once the word is set every later
+ * collective of the communicator poisons at once (no further spinning).  msgl_p2p_error reads the word (synchronises
+ * the device); msgl_p2p_error_async enqueues a 4-byte copy of it into pinned host memory on `stream` for hosts that
+ * poll every few steps (kernel.P2PCommunicator.poll_error raises).  msgl_p2p_set_spin_limit: polls per barrier before
+ * giving up (default 40 M ~ tens of seconds). */
 int msgl_p2p_error(msgl_p2p_t comm);
+int msgl_p2p_error_async(msgl_p2p_t comm, void* pinned_host_u32, void* stream);
+int msgl_p2p_set_spin_limit(msgl_p2p_t comm, uint32_t spins);
 void* msgl_p2p_get_buffer(msgl_p2p_t comm);
 int msgl_p2p_destroy(msgl_p2p_t comm);   /* detaches; buffers stay mapped until msgl_p2p_release_all / exit */
 int msgl_p2p_release_all(void);

@@ -79,6 +79,8 @@ HIP_SIGNATURES = {
     "msgl_p2p_all_reduce_sum": (_i, [_p, _p, _sz, _i, _p]),
     "msgl_p2p_all_gather": (_i, [_p, _p, _p, _sz, _i, _p]),
     "msgl_p2p_error": (_i, [_p]),
+    "msgl_p2p_error_async": (_i, [_p, _p, _p]),
+    "msgl_p2p_set_spin_limit": (_i, [_p, C.c_uint32]),
     "msgl_p2p_get_buffer": (_p, [_p]),
     "msgl_p2p_destroy": (_i, [_p]),
     "msgl_p2p_release_all": (_i, []),

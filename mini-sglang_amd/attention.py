@@ -85,6 +85,7 @@ class HipAttnBackend:
         self.device = self.kvcache.device
         self.head_dim = config.head_dim
         self.scale = config.head_dim ** -0.5
+        self.tp_size = tp_size
         self.qo_heads = config.num_qo_heads // tp_size
         self.kv_heads = max(config.num_kv_heads // tp_size, 1)
         self.max_bs = int(ctx.page_table.shape[0])
@@ -133,6 +134,14 @@ class HipAttnBackend:
 
     # ------------------------------------------------------------------ metadata
     def prepare_metadata(self, batch: Any) -> None:
+        if self.tp_size > 1:
+            # driven by the reference's scheduler nobody else sees the communicator once decode runs from captured
+            # graphs: every 16th step look at the peer-to-peer error word (one 4-byte async copy; raises on a timeout)
+            self._md_calls = getattr(self, "_md_calls", 0) + 1
+            if self._md_calls % 16 == 0:
+                from .kernel import poll_communicator_errors
+
+                poll_communicator_errors(sync=False)
         reqs = batch.padded_reqs
         bs = len(reqs)
         seqlens_q = np.fromiter((r.extend_len for r in reqs), dtype=np.int64, count=bs)

@@ -50,9 +50,17 @@ struct P2PPeers {
   unsigned char* base[kP2PMaxRanks];  // mapped buffers, [rank]
 };
 
-__device__ __forceinline__ void p2p_barrier(const P2PPeers& peers, int rank, int world, int phase, bool release) {
+// Returns true if this barrier -- or an earlier one of this communicator (`bad` in, the sticky error word) -- timed
+// out.  The caller then POISONS what its block would have written (all-ones = NaN in bf16 / fp16): a collective
+// whose barrier gave up must never hand back a plausible partial sum (a lagging or dead peer would otherwise turn
+// into silently diverging replicas).  Once the error word is set no later barrier spins: every following collective
+// poisons at once and the host raises at its next poll (kernel.P2PCommunicator.poll_error).
+__device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int world, int phase, bool release,
+                                            uint32_t spin_limit, bool bad) {
+  __shared__ int s_bad;
   P2PHeader* self = reinterpret_cast<P2PHeader*>(peers.base[rank]);
   const int b = blockIdx.x;
+  if (threadIdx.x == 0) s_bad = bad ? 1 : 0;
   __syncthreads();  // everything this block did before the barrier is issued
   if (release) __threadfence_system();
   uint32_t seq = 0;
@@ -61,17 +69,28 @@ __device__ __forceinline__ void p2p_barrier(const P2PPeers& peers, int rank, int
     P2PHeader* peer = reinterpret_cast<P2PHeader*>(peers.base[threadIdx.x]);
     __hip_atomic_store(&peer->flag[b][phase][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t spins = 0;
-    while (__hip_atomic_load(&self->flag[b][phase][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    while (!bad &&
+           __hip_atomic_load(&self->flag[b][phase][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > kP2PSpinLimit) {
+      if (++spins > spin_limit) {
         __hip_atomic_store(&self->error, 1u + (uint32_t)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s_bad = 1;
         break;
       }
     }
   }
   __syncthreads();
+  const bool out = s_bad != 0;
   if (threadIdx.x == 0) self->seq[b][phase] = seq;
+  return out;
 }
+
+__device__ __forceinline__ bool p2p_sticky_error(const P2PPeers& peers, int rank) {
+  return __hip_atomic_load(&reinterpret_cast<P2PHeader*>(peers.base[rank])->error, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+}
+
+__device__ __forceinline__ U4 p2p_poison() { return U4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}; }
 
 template <typename T>
 __device__ __forceinline__ void acc8(float (&a)[8], const U4& v) {
@@ -96,19 +115,23 @@ __device__ __forceinline__ void block_slice(int64_t n, int64_t& lo, int64_t& hi)
 // data: in place, `packs` x 16 B.  area A (copy of the input) at base + header, area B (two-shot results) behind it.
 template <typename T, bool TWO_SHOT>
 __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers peers, int rank, int world, U4* data,
-                                                                     int64_t packs, int64_t area_packs) {
+                                                                     int64_t packs, int64_t area_packs,
+                                                                     uint32_t spin_limit) {
   U4* mine = reinterpret_cast<U4*>(peers.base[rank] + kP2PHeaderBytes);
+  bool bad = p2p_sticky_error(peers, rank);
   if constexpr (!TWO_SHOT) {
     int64_t lo, hi;
     block_slice(packs, lo, hi);
     for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) mine[i] = data[i];
-    p2p_barrier(peers, rank, world, 0, true);
+    bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
     for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) {
       float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int r = 0; r < world; ++r) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes)[i]);
-      data[i] = pack8f<T>(a);
+      data[i] = bad ? p2p_poison() : pack8f<T>(a);
     }
-    p2p_barrier(peers, rank, world, 1, false);  // nobody refills its copy while a peer still reads it
+    bad = p2p_barrier(peers, rank, world, 1, false, spin_limit, bad);  // nobody refills its copy while a peer still reads it
+    if (bad)
+      for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) data[i] = p2p_poison();
   } else {
     const int64_t chunk = (packs + world - 1) / world;  // packs per owner
     // copy in: for every chunk c this block's slice of c (what the peers' block b will read from me)
@@ -118,7 +141,7 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
       block_slice(cn, lo, hi);
       for (int64_t i = c0 + lo + threadIdx.x; i < c0 + hi; i += kP2PThreads) mine[i] = data[i];
     }
-    p2p_barrier(peers, rank, world, 0, true);
+    bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
     // reduce-scatter: my chunk, summed in rank order, into my result area
     const int64_t m0 = min((int64_t)rank * chunk, packs), mn = min(chunk, packs - m0);
     int64_t lo, hi;
@@ -129,32 +152,44 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
       for (int r = 0; r < world; ++r) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes)[i]);
       res[i] = pack8f<T>(a);
     }
-    p2p_barrier(peers, rank, world, 1, true);
+    bad = p2p_barrier(peers, rank, world, 1, true, spin_limit, bad);
     // all-gather of the reduced chunks from their owners
     for (int c = 0; c < world; ++c) {
       const int64_t c0 = min((int64_t)c * chunk, packs), cn = min(chunk, packs - c0);
       int64_t l2, h2;
       block_slice(cn, l2, h2);
       const U4* src = reinterpret_cast<const U4*>(peers.base[c] + kP2PHeaderBytes) + area_packs;
-      for (int64_t i = c0 + l2 + threadIdx.x; i < c0 + h2; i += kP2PThreads) data[i] = src[i];
+      for (int64_t i = c0 + l2 + threadIdx.x; i < c0 + h2; i += kP2PThreads) data[i] = bad ? p2p_poison() : src[i];
     }
-    p2p_barrier(peers, rank, world, 2, false);
+    bad = p2p_barrier(peers, rank, world, 2, false, spin_limit, bad);
+    if (bad)
+      for (int c = 0; c < world; ++c) {
+        const int64_t c0 = min((int64_t)c * chunk, packs), cn = min(chunk, packs - c0);
+        int64_t l2, h2;
+        block_slice(cn, l2, h2);
+        for (int64_t i = c0 + l2 + threadIdx.x; i < c0 + h2; i += kP2PThreads) data[i] = p2p_poison();
+      }
   }
 }
 
 // dst[r * packs + i] = src_of_rank_r[i]
 __global__ __launch_bounds__(kP2PThreads) void p2p_all_gather_kernel(P2PPeers peers, int rank, int world, U4* dst,
-                                                                     const U4* src, int64_t packs) {
+                                                                     const U4* src, int64_t packs,
+                                                                     uint32_t spin_limit) {
   U4* mine = reinterpret_cast<U4*>(peers.base[rank] + kP2PHeaderBytes);
+  bool bad = p2p_sticky_error(peers, rank);
   int64_t lo, hi;
   block_slice(packs, lo, hi);
   for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) mine[i] = src[i];
-  p2p_barrier(peers, rank, world, 0, true);
+  bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
   for (int r = 0; r < world; ++r) {
     const U4* from = reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) dst[(int64_t)r * packs + i] = from[i];
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) dst[(int64_t)r * packs + i] = bad ? p2p_poison() : from[i];
   }
-  p2p_barrier(peers, rank, world, 1, false);
+  bad = p2p_barrier(peers, rank, world, 1, false, spin_limit, bad);
+  if (bad)
+    for (int r = 0; r < world; ++r)
+      for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) dst[(int64_t)r * packs + i] = p2p_poison();
 }
 
 }  // namespace msgl
@@ -172,6 +207,7 @@ struct msgl_p2p {
   P2PPeers peers;
   size_t one_shot_max = 256 << 10;
   int blocks = 32;
+  uint32_t spin_limit = kP2PSpinLimit;  // polls of a peer's flag before a barrier gives up (msgl_p2p_set_spin_limit)
 };
 
 #define P2P_HIP(call, what)                                                     \
@@ -269,7 +305,7 @@ extern "C" int msgl_p2p_all_reduce_sum(msgl_p2p_t c, void* data, size_t count, i
   const int64_t packs = (int64_t)(bytes / 16), area = (int64_t)(c->max_bytes / 16);
   const bool two = bytes > c->one_shot_max && c->world > 1;
   const dim3 grid((unsigned)c->blocks), block(kP2PThreads);
-#define MSGL_P2P(T, TWO) p2p_all_reduce_kernel<T, TWO><<<grid, block, 0, s>>>(c->peers, c->rank, c->world, (U4*)data, packs, area)
+#define MSGL_P2P(T, TWO) p2p_all_reduce_kernel<T, TWO><<<grid, block, 0, s>>>(c->peers, c->rank, c->world, (U4*)data, packs, area, c->spin_limit)
   if (dtype == MSGL_BF16) { if (two) MSGL_P2P(BF16, true); else MSGL_P2P(BF16, false); }
   else { if (two) MSGL_P2P(FP16, true); else MSGL_P2P(FP16, false); }
 #undef MSGL_P2P
@@ -288,7 +324,8 @@ extern "C" int msgl_p2p_all_gather(msgl_p2p_t c, void* dst, const void* src, siz
   if (int rc = p2p_ready(c, "p2p_all_gather")) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   p2p_all_gather_kernel<<<dim3((unsigned)c->blocks), dim3(kP2PThreads), 0, s>>>(c->peers, c->rank, c->world, (U4*)dst,
-                                                                              (const U4*)src, (int64_t)(bytes / 16));
+                                                                              (const U4*)src, (int64_t)(bytes / 16),
+                                                                              c->spin_limit);
   MSGL_CHECK_LAUNCH("p2p_all_gather");
   return MSGL_OK;
 }
@@ -300,6 +337,24 @@ extern "C" int msgl_p2p_error(msgl_p2p_t c) {
   P2P_HIP(hipMemcpy(&e, &reinterpret_cast<P2PHeader*>(c->local)->error, sizeof(e), hipMemcpyDeviceToHost),
           "p2p_error: read");
   return (int)e;
+}
+
+// The same word without a device synchronisation: a 4-byte device-to-host copy enqueued on `stream` into
+// `host_dst` (pinned host memory owned by the caller, read by it after a later synchronisation of that stream).
+extern "C" int msgl_p2p_error_async(msgl_p2p_t c, void* host_dst, void* stream) {
+  MSGL_REQUIRE(c && host_dst, "p2p_error_async: null pointer");
+  P2P_HIP(hipMemcpyAsync(host_dst, &reinterpret_cast<P2PHeader*>(c->local)->error, sizeof(uint32_t),
+                         hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)),
+          "p2p_error_async: copy");
+  return MSGL_OK;
+}
+
+// Polls of a peer's flag (each ~ s_sleep 2 + one uncached load) before a barrier gives up; default 40 M (tens of
+// seconds: a peer may legitimately lag by a capture or a tuning pass).  Tests lower it.
+extern "C" int msgl_p2p_set_spin_limit(msgl_p2p_t c, uint32_t spins) {
+  MSGL_REQUIRE(c && spins > 0, "p2p_set_spin_limit: bad argument");
+  c->spin_limit = spins;
+  return MSGL_OK;
 }
 
 extern "C" void* msgl_p2p_get_buffer(msgl_p2p_t c) {

@@ -144,8 +144,14 @@ __device__ __forceinline__ float wave_max(float x) {
 }
 
 // silu(g) * u in fp32: the one expression shared by the activation kernels and the fused projection epilogue
-// (csrc/gemm_g3.hip) so that they agree bit for bit
-__device__ __forceinline__ float silu_mul_f32(float g, float u) { return (g / (1.0f + __expf(-g))) * u; }
+// (csrc/gemm_g3.hip) so that they agree bit for bit.  The empty asm pins the fp32 product in a register: without it
+// hipcc fuses "multiply, then round to fp16" into one v_fma_mixlo_f16 where the second factor came from an fp16 value
+// (single rounding) but not elsewhere (fp32 product, then rounded again): 1-ulp differences between call sites.
+__device__ __forceinline__ float silu_mul_f32(float g, float u) {
+  float p = (g / (1.0f + __expf(-g))) * u;
+  asm("" : "+v"(p));
+  return p;
+}
 
 __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
 

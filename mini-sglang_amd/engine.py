@@ -211,9 +211,12 @@ class Engine:
         free_before = torch.cuda.mem_get_info(self.device)[0]
         free_before = self._agreed_free_memory(free_before)
         comm = Communicator(cfg.comm, cfg.tp_size, side=cfg.comm_side)
+        # two collectives of ONE communicator must never be in flight at once (shared flags / sequence counters; RCCL is
+        # not safe across two streams either): without a second communicator the token halves run serially
+        overlap = cfg.comm_overlap and not (cfg.tp_size > 1 and cfg.comm_split_tokens > 0 and cfg.comm_side is None)
         self.model = DenseDecoder(cfg.model, dtype=cfg.dtype, device=self.device, tp_rank=cfg.tp_rank,
                                   tp_size=cfg.tp_size, seed=cfg.seed, comm=comm, fused=cfg.fused_qkv_path,
-                                  comm_split_tokens=cfg.comm_split_tokens, comm_overlap=cfg.comm_overlap)
+                                  comm_split_tokens=cfg.comm_split_tokens, comm_overlap=overlap)
         torch.cuda.synchronize(self.device)
         free_after = self._agreed_free_memory(torch.cuda.mem_get_info(self.device)[0])
 
@@ -270,9 +273,20 @@ class Engine:
             req.complete_one()
         next_tokens_gpu = self.sampler.sample(logits[: batch.size], args).to(torch.int32)
         next_tokens_cpu = next_tokens_gpu.to("cpu", non_blocking=True)
+        if self.cfg.tp_size > 1:  # a peer-to-peer barrier that gave up poisons its output: make that an exception
+            self._forwards = getattr(self, "_forwards", 0) + 1
+            if self._forwards % 8 == 0:
+                self._poll_comm_errors(sync=False)
         ev = torch.cuda.Event()
         ev.record(self.stream)
         return ForwardOutput(next_tokens_gpu, next_tokens_cpu, ev)
 
+    def _poll_comm_errors(self, sync: bool) -> None:
+        for c in (self.cfg.comm, self.cfg.comm_side):
+            if c is not None and hasattr(c, "poll_error"):
+                c.poll_error(sync)
+
     def shutdown(self) -> None:
         self.graph_runner.destroy()
+        if self.cfg.tp_size > 1:
+            self._poll_comm_errors(sync=True)

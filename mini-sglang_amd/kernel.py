@@ -176,6 +176,37 @@ class P2PCommunicator:
         """0, or 1 + the barrier phase that timed out (sticky; synchronises the device)."""
         return int(self._lib.msgl_p2p_error(self._handle))
 
+    def set_spin_limit(self, spins: int) -> None:
+        """Flag polls per barrier before it gives up (default 40 M ~ tens of seconds)."""
+        _lib.check(self._lib.msgl_p2p_set_spin_limit(self._handle, int(spins)), "p2p_set_spin_limit")
+
+    def poll_error(self, sync: bool = False) -> None:
+        """Raise if a barrier of this communicator ever timed out (its kernels then returned NaN-poisoned outputs, never
+        a partial sum).  sync=False costs one 4-byte async copy: it enqueues a read of the device's error word on the
+        current stream and examines the value the PREVIOUS poll fetched (complete by now in any loop that synchronises
+        once per step, as the token copy of a decode step does); sync=True reads the word now (device synchronise)."""
+        if not self._handle:
+            return
+        if sync:
+            e = self.error()
+        else:
+            if getattr(self, "_err_host", None) is None:
+                self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._err_event = None
+            e = 0
+            if self._err_event is not None and self._err_event.query():
+                e = int(self._err_host[0])
+                self._err_event = None
+            if e == 0 and self._err_event is None:
+                _lib.check(self._lib.msgl_p2p_error_async(self._handle, self._err_host.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), "p2p_error_async")
+                self._err_event = torch.cuda.Event()
+                self._err_event.record()
+        if e:
+            raise _lib.MsglError(
+                f"peer-to-peer collective: rank {self.rank} of {self.world_size} gave up waiting for a peer at barrier "
+                f"phase {e - 1} (spin limit reached); outputs of that and every later collective are NaN-poisoned")
+
     def get_buffer(self) -> int:
         return int(self._lib.msgl_p2p_get_buffer(self._handle) or 0)
 
@@ -183,6 +214,17 @@ class P2PCommunicator:
         if self._handle:
             self._lib.msgl_p2p_destroy(self._handle)
             self._handle = ctypes.c_void_p()
+
+
+_LIVE_COMMUNICATORS: set = set()  # communicators init_pynccl handed out and nobody destroyed yet
+
+
+def poll_communicator_errors(sync: bool = False) -> None:
+    """poll_error() of every live communicator: the per-step hook of hosts that own no communicator object themselves
+    (the attention backend calls it every few prepare_metadata calls when driven by the reference's scheduler, whose
+    captured decode graphs never pass through Python's all_reduce)."""
+    for c in list(_LIVE_COMMUNICATORS):
+        c.poll_error(sync)
 
 
 class HybridCommunicator:
@@ -194,6 +236,7 @@ class HybridCommunicator:
         self.p2p, self.rccl = p2p, rccl
         self.rank = (p2p or rccl).rank
         self.world_size = (p2p or rccl).world_size
+        _LIVE_COMMUNICATORS.add(self)
 
     def all_reduce(self, input: torch.Tensor, op: Literal["sum"] = "sum") -> None:
         if self.p2p is not None and (self.rccl is None or self.p2p.fits(input)):
@@ -208,10 +251,19 @@ class HybridCommunicator:
     def get_buffer(self) -> int:
         return (self.p2p or self.rccl).get_buffer()
 
+    def poll_error(self, sync: bool = False) -> None:
+        """Raise if a peer-to-peer barrier timed out (see P2PCommunicator.poll_error); RCCL reports through its calls."""
+        if self.p2p is not None:
+            self.p2p.poll_error(sync)
+
     def destroy(self) -> None:
-        for c in (self.p2p, self.rccl):
-            if c is not None:
-                c.destroy()
+        try:
+            self.poll_error(sync=True)  # a timed-out barrier must not pass unnoticed because nobody polled
+        finally:
+            for c in (self.p2p, self.rccl):
+                if c is not None:
+                    c.destroy()
+            _LIVE_COMMUNICATORS.discard(self)
 
 
 PyNCCLCommunicator = HybridCommunicator
@@ -224,13 +276,18 @@ def create_unique_id() -> bytes:
 
 
 def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int = 0,
-                backend: str = "hybrid") -> HybridCommunicator:
+                backend: Optional[str] = None) -> HybridCommunicator:
     """P/kernel/pynccl.py:47-78.  backend: "hybrid" (peer-to-peer buffers of max_size_bytes + RCCL for larger
     messages), "rccl" (library only), "p2p" (mapped buffers only: every message must fit; the only choice when two
     ranks share a device).  RCCL bootstrap as in the reference: rank 0 creates the unique id, broadcast over the CPU
     (gloo) group."""
+    import os
+
     import torch.distributed as dist
 
+    # the reference calls init_pynccl(tp_rank, tp_size, tp_cpu_group, max_size_bytes) (P/distributed/impl.py:81-88): the
+    # backend of a drop-in run is chosen by the environment
+    backend = backend or os.environ.get("MSGL_COMM_BACKEND", "hybrid")
     if backend not in ("hybrid", "rccl", "p2p"):
         raise ValueError(backend)
     rccl = p2p = None
@@ -263,4 +320,4 @@ def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int
 
 
 __all__ = ["indexing", "fast_compare_key", "store_cache", "init_pynccl", "PyNCCLCommunicator", "RcclCommunicator",
-           "P2PCommunicator", "HybridCommunicator"]
+           "P2PCommunicator", "HybridCommunicator", "poll_communicator_errors"]

@@ -356,7 +356,20 @@ def _install_tune_before_capture() -> None:
                 torch.cuda.synchronize(self.device)
         if _STATE["fast_linear"] and os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1":
             _STATE["deferred_reduce_weights"] = _deferred_reduce_weights(model)
-        return reference_capture(self, max_seq_len, vocab_size, model)
+        out = reference_capture(self, max_seq_len, vocab_size, model)
+        try:
+            import torch
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # kernel search and capture take a rank-dependent time, and the device-side barriers of the peer-to-peer
+                # collectives give up after a bounded spin: the ranks meet on the CPU before the first forward (the
+                # reference's default group is its gloo TP group when pynccl is on, P/engine/engine.py:113-126)
+                torch.cuda.synchronize(self.device)
+                dist.barrier()
+        except ImportError:
+            pass
+        return out
 
     _capture_graphs._msgl_tuned = True  # type: ignore[attr-defined]
     GraphRunner._capture_graphs = _capture_graphs

@@ -131,6 +131,9 @@ class DenseDecoder:
         # the first half (side stream, second communicator) overlaps the GEMM of the second (0 = never).  Meant for
         # prefill chunks: a decode batch would stream the weights twice for nothing (its GEMMs are weight-bound).
         self.comm_split_tokens = comm_split_tokens if tp_size > 1 else 0
+        if self.comm_split_tokens and comm_overlap and self.comm.side is None:
+            raise ValueError("comm_overlap with comm_split_tokens > 0 needs a second communicator (Communicator.side): two "
+                             "collectives of one communicator must never be in flight at once")
         self.comm_overlap = comm_overlap
         self.side_stream = torch.cuda.Stream(device=device) if (self.comm_split_tokens and comm_overlap) else None
         D = cfg.head_dim

@@ -134,6 +134,45 @@ def run_worker(spec: Dict[str, Any], timeout: float = 900.0) -> Dict[str, Any]:
         return rec
 
 
+def run_tp_workers(spec: Dict[str, Any], tp_size: int, timeout: float = 900.0) -> list:
+    """The same scenario as `tp_size` rank processes (one reference `LLM` each, tp_info = (rank, tp_size)); on a box
+    with fewer GPUs than ranks they share device 0 over the peer-to-peer communicator.  Returns the ranks' records."""
+    import socket
+
+    import torch
+
+    ref = reference_root()
+    assert ref is not None, "no importable reference (run oracle/build_ref.sh in the build container)"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    spec = dict(spec, tp_size=tp_size, port=port)
+    with tempfile.TemporaryDirectory(prefix="msgl_refdrive_tp_") as td:
+        spec_path, out_path = Path(td) / "spec.json", Path(td) / "out.pt"
+        spec_path.write_text(json.dumps(spec))
+        procs = []
+        for r in range(tp_size):
+            env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MSGL_REFDRIVE_RANK=str(r),
+                       GLOO_SOCKET_IFNAME="lo")
+            env.pop("MSGL_GEMM_TUNE", None)
+            procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "refdrive_worker.py"), str(spec_path),
+                                           str(out_path), str(ref)], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True))
+        logs, failed = [], False
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, _ = p.communicate()
+                failed = True
+            logs.append(o)
+            failed |= p.returncode != 0
+        if failed or not all(Path(f"{out_path}.{r}").exists() for r in range(tp_size)):
+            raise AssertionError("reference-driven tp workers failed:\n" + "\n=====\n".join(l[-4000:] for l in logs))
+        return [torch.load(f"{out_path}.{r}", weights_only=False) for r in range(tp_size)]
+
+
 def offline_bench_requests(n: int, seed: int = 0, max_out: Optional[int] = None):
     """First `n` requests of the reference's offline benchmark (benchmark/offline/bench.py:11-31: seed(0), 256
     prompts of randint(100,1024) ids in [0,10000], max_tokens randint(100,1024)), generated in the same call

@@ -35,6 +35,58 @@ def logits_summary(logits):
                 checksum=(bits.sum(-1) + (bits * weights).sum(-1)).cpu(), dtype=str(logits.dtype))
 
 
+def replay_through_repo_engine(spec, forwards, ref_engine, tp_rank, tp_size, rec):
+    """Inside the rank processes of a tp > 1 scenario: the recorded batches through THIS repository's Engine at the
+    same tp (same ranks, a second peer-to-peer communicator), bit-compared with what the reference's engine produced;
+    rank 0 also replays them through a tp = 1 engine (all weights) for the tolerance check."""
+    import torch
+    import torch.distributed as dist
+    from safetensors.torch import load_file
+
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.kernel import init_pynccl
+    from mini_sglang_amd.model import PRESETS
+    from replay_util import replay_forward
+
+    kw, dev = spec["llm_kwargs"], ref_engine.device
+    state = load_file(str(Path(spec["model_dir"]) / "model.safetensors"))
+    group = dist.group.WORLD
+    max_bytes = kw.get("max_extend_tokens", 8192) * PRESETS[spec["model"]].hidden_size * 2
+
+    def build(size, rank, comm):
+        cfg = EngineConfig(model=PRESETS[spec["model"]], dtype=torch.bfloat16, tp_rank=rank, tp_size=size,
+                           max_running_req=kw["max_running_req"], page_size=kw["page_size"],
+                           cuda_graph_bs=list(rec["graph_bs"]), max_seq_len_override=kw["max_seq_len_override"],
+                           num_page_override=rec["num_pages"], fused_qkv_path=True, gemm_tune="off", comm=comm,
+                           tp_cpu_group=group if size > 1 else None)
+        eng = Engine(cfg, dev)
+        eng.model.load_hf_state(state)
+        return eng
+
+    out = {}
+    comm = init_pynccl(tp_rank=tp_rank, tp_size=tp_size, tp_cpu_group=group, max_size_bytes=max_bytes, backend="p2p")
+    eng = build(tp_size, tp_rank, comm)
+    same, tp_logits = [], []
+    for f in forwards:
+        lg = replay_forward(eng, {k: v for k, v in f.items()})
+        mine = logits_summary(lg)
+        r = f["summary"]
+        same.append(bool(r["dtype"] == mine["dtype"] and torch.equal(r["argmax"], mine["argmax"])
+                         and torch.equal(r["top2"], mine["top2"]) and torch.equal(r["checksum"], mine["checksum"])))
+        tp_logits.append(lg.float().cpu())
+    out["bit_identical"] = same
+    out["comm_error"] = comm.p2p.error()
+    eng.shutdown()
+    dist.barrier()
+    comm.destroy()
+    if tp_rank == 0:
+        eng1 = build(1, 0, None)
+        out["max_abs_vs_tp1"] = [float((replay_forward(eng1, f).float().cpu() - t).abs().max()) for f, t in zip(forwards, tp_logits)]
+        eng1.shutdown()
+    dist.barrier()
+    return out
+
+
 def main() -> None:
     spec_path, out_path, ref_root = sys.argv[1:4]
     spec = json.loads(Path(spec_path).read_text())
@@ -42,6 +94,13 @@ def main() -> None:
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    tp_size = int(spec.get("tp_size", 1))
+    tp_rank = int(os.environ.get("MSGL_REFDRIVE_RANK", "0"))
+    if tp_size > 1:
+        out_path = f"{out_path}.{tp_rank}"
+        os.environ.setdefault("MSGL_COMM_BACKEND", spec.get("comm_backend", "p2p"))
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 
     import mini_sglang_amd.minisgl_plugin as plugin
 
@@ -71,9 +130,11 @@ def main() -> None:
     # worker processes on one box would race for it
     from minisgl.engine.config import EngineConfig
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = spec.get("port")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
     EngineConfig.distributed_addr = property(lambda self: f"tcp://127.0.0.1:{port}")  # type: ignore[assignment]
 
     from minisgl.core import SamplingParams
@@ -83,7 +144,29 @@ def main() -> None:
     kw.setdefault("attention_backend", "hip")
     kw["use_dummy_weight"] = spec.get("weights", "seeded") == "dummy"
     t0 = time.perf_counter()
-    llm = LLM(model_dir, **kw)
+    if tp_size == 1:
+        llm = LLM(model_dir, **kw)
+    else:
+        # The reference's offline `LLM` hard-wires tp_info = (0, 1) (P/llm/llm.py:31); its TP ranks are scheduler
+        # processes fed over ZMQ.  Here every rank is an offline LLM with its real tp_info (offline mode takes the same
+        # early exit on every rank, P/scheduler/io.py:30-33): the replicated schedulers see the same request list.
+        # All ranks share ONE GPU on a 1-GPU box: the reference picks its device as f"cuda:{tp_info.rank}"
+        # (P/engine/engine.py:35) -- the rank below formats as "0" there and is the true rank everywhere else.
+        from minisgl.distributed import DistributedInfo
+        from minisgl.scheduler import Scheduler, SchedulerConfig
+
+        class _RankOnDevice0(int):
+            def __format__(self, spec_):
+                return "0"
+
+        class TPLLM(LLM):
+            def __init__(self, model_path, tp_info, dtype=torch.bfloat16, **kwargs):
+                config = SchedulerConfig(model_path=model_path, tp_info=tp_info, dtype=dtype, offline_mode=True, **kwargs)
+                Scheduler.__init__(self, config)
+                self.pending_requests, self.status_map, self.counter = [], {}, 0
+
+        share = torch.cuda.device_count() < tp_size
+        llm = TPLLM(model_dir, DistributedInfo(_RankOnDevice0(tp_rank) if share else tp_rank, tp_size), **kw)
     init_s = time.perf_counter() - t0
     engine = llm.engine
 
@@ -154,6 +237,18 @@ def main() -> None:
                                                     "_msgl_fused", False)),
                gemm_report=plugin.gemm_report(), prefix_cache=type(cm.prefix_cache).__name__, deferred_reduce_weights=len(plugin._STATE["deferred_reduce_weights"]), free_pages_end=int(len(cm.free_slots)),
                evictable_end=int(cm.prefix_cache.size_info.evictable_size), device=torch.cuda.get_device_name(0))
+    rec["tp_rank"], rec["tp_size"] = tp_rank, tp_size
+    if tp_size > 1:
+        import minisgl.distributed.impl as dimpl
+
+        plug = dimpl.DistributedCommunicator.plugins[-1]
+        comm = getattr(plug, "comm", None)
+        rec["comm_class"] = type(comm).__name__
+        rec["comm_p2p_error"] = comm.p2p.error() if getattr(comm, "p2p", None) is not None else None
+        rec["comm_has_rccl"] = getattr(comm, "rccl", None) is not None
+        rec["interleaved_mlps"] = plugin._STATE.get("interleaved_mlps")
+    if spec.get("replay_repo_engine"):
+        rec["repo_replay"] = replay_through_repo_engine(spec, forwards, engine, tp_rank, tp_size, rec)
     try:
         cm.check_integrity()
         rec["integrity"] = "ok"

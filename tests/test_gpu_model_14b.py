@@ -1,0 +1,154 @@
+"""Parity on the configuration the metric is quoted on (VERDICT r2 "next" 1a): Qwen3-14B *dimensions* (hidden 5120,
+40 / 8 heads of 128, intermediate 17408, vocab 151936; P/models/qwen3.py:18-81) at reduced depth, the full decode batch
+of 256 through the captured graph WITH THE KERNEL PLANS THE TUNER PICKS at M = 256 (k-sliced full-batch projections
+whose reduce is done by the next norm / the qk-norm pass, the fused gate_up + SiLU.mul launch or the library's gate_up),
+a chunked prefill in front, teacher-forced against oracle/ref_model.py; and every projection of one such layer on the
+oracle's own input, in bf16 ulp of the oracle value.
+"""
+import random
+
+import pytest
+import torch
+
+import parity_stats
+from oracle import ref_model, ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(layers):
+    from mini_sglang_amd.model import PRESETS, ModelConfig
+
+    m = PRESETS["qwen3-14b"]
+    return ModelConfig(layers, m.num_qo_heads, m.num_kv_heads, m.head_dim, m.hidden_size, m.vocab_size,
+                       m.intermediate_size, name="Qwen3-14B dims, reduced depth")
+
+
+def test_qwen3_14b_dims_full_decode_batch_with_tuned_plans_vs_oracle(dev):
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.offline import OfflineRunner
+    from replay_util import record_offline_runner
+
+    layers, B = 4, 256
+    m = _cfg(layers)
+    cfg = EngineConfig(model=m, dtype=torch.bfloat16, max_running_req=B, page_size=256, cuda_graph_bs=[B],
+                       max_seq_len_override=512, num_page_override=B + 8, seed=42, gemm_tune="heuristic")
+    eng = Engine(cfg, dev)
+    try:
+        eng.kv_cache._kv_buffer.zero_()
+        plans = {r["name"]: r for r in eng.gemm_report if r["M"] == B}
+        chosen = {k: r["kernel"][:70] for k, r in plans.items()}
+        print(f"\n[14B dims] kernels at M = {B}: {chosen}")
+        # the point of this test: the hand-written full-batch plans (not the library heuristic) carry the decode batch
+        sliced = [k for k in ("qkv", "o", "down") if ops._M256_PLAN and plans[k].get("m256_used")
+                  and plans[k]["m256_plan"][1] == 0 and plans[k]["m256_plan"][2] > 1]
+        assert len(sliced) >= 2, f"expected k-sliced full-batch plans for the small projections, got {chosen}"
+        rnd = random.Random(0)
+        prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(1, 8))] for _ in range(B)]
+        runner = OfflineRunner(eng, max_extend_tokens=1024, seed=1)
+        rec = []
+        record_offline_runner(runner, eng, rec)
+        sp = [SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True) for _ in prompts]
+        runner.generate(prompts, sp)
+        phases = [(f["phase"], f["size"], bool(f["graph"])) for f in rec]
+        assert [p[0] for p in phases].count("prefill") >= 2, phases           # chunked prefill
+        assert phases[-1] == ("decode", B, True) and phases[-2] == ("decode", B, True), phases  # full batch, graph replay
+        w = ref_model.weights_from_device_model(eng.model)
+        table = eng.page_table.cpu()
+        slots = eng.kv_cache._kv_buffer.shape[2] * eng.kv_cache._kv_buffer.shape[3]
+        kp = [torch.zeros((slots, m.num_kv_heads, m.head_dim), dtype=torch.bfloat16) for _ in range(layers)]
+        vp = [torch.zeros_like(k) for k in kp]
+        stats, agree, total, sure_bad = {}, 0, 0, 0
+        # logit std 1.43 (hidden 5120, N(0, 0.02^2) LM head): one bf16 ulp of a typical logit is 7.8e-3 .. 1.6e-2.  Measured
+        # (printed below): max 1.09e-1, p99 4.7e-2, mean 1.45e-2 -- THE SAME for the eager prefill forwards (library
+        # GEMMs, no split-K) and the graph-replayed full decode batch on the tuned plans: the error is the bf16 pipeline
+        # against an fp32-accumulating oracle at this width, not the plans.  Bounds = measured + margin.
+        tol = 1.5e-1
+        for i, f in enumerate(rec):
+            k_lens, q_lens = f["device_lens"], [d - c for d, c in zip(f["device_lens"], f["cached_lens"])]
+            want = ref_model.forward(m, w, f["input_ids"], f["positions"], f["out_loc"], kp, vp, table, f["rows"], k_lens,
+                                     q_lens, f["phase"] == "prefill").float()[: f["size"]]
+            st = parity_stats.logit_error_stats(f["logits"], want)
+            stats = parity_stats.merge_stats(stats, st)
+            print(f"[14B dims] forward {i} {f['phase']:7s} size {f['size']:3d} graph {f['graph']}: {parity_stats.fmt(st)}")
+            assert st["max_abs"] <= tol, (i, parity_stats.fmt(st))
+            top2 = want.topk(2, dim=-1).values
+            sure = (top2[:, 0] - top2[:, 1]) > 2 * tol
+            same = f["logits"].argmax(-1) == want.argmax(-1)
+            sure_bad += int((~same[sure]).sum())
+            agree, total = agree + int(same.sum()), total + same.numel()
+        print(f"[14B dims, {layers} layers, B = {B}] {parity_stats.fmt(stats)}; argmax agreement {agree}/{total}")
+        assert sure_bad == 0 and agree >= 0.9 * total
+        assert stats["p99_abs"] <= 6e-2 and stats["mean_abs"] <= 2e-2, parity_stats.fmt(stats)
+        # the tuned full-batch forwards are no worse than the eager library-GEMM forwards of the same model
+        eager = [f for f in rec if not f["graph"]]
+        assert eager and all(f["phase"] == "prefill" for f in eager)
+        dev_k = eng.kv_cache._kv_buffer[0].cpu().view(layers, slots, m.num_kv_heads, m.head_dim)
+        used = torch.cat([f["out_loc"][: sum(d - c for d, c in zip(f["device_lens"][: f["size"]], f["cached_lens"][: f["size"]]))]
+                          for f in rec]).long().unique()
+        for li in (0, layers - 1):
+            torch.testing.assert_close(dev_k[li][used].float(), kp[li][used].float(), atol=6e-2, rtol=6e-2)
+    finally:
+        eng.shutdown()
+        ops.reset_gemm_plans()
+
+
+def test_qwen3_14b_layer_projections_with_tuned_plans_each_on_the_oracles_input(dev):
+    """The four projections of one Qwen3-14B layer at M = 256 through whatever the pre-capture search plans for them
+    (library solution, k-sliced full-batch kernel + slab hand-off, fused SiLU.mul epilogue), each fed the ORACLE's input
+    for that op: <= 2 bf16 ulp of the oracle value for the projections, <= 3 for projection + activation; the slab
+    hand-offs equal reduce-then-op bit for bit at these dims."""
+    import torch.nn.functional as F
+
+    from mini_sglang_amd import flashinfer_compat as fi
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.gemm_plan import tune_projection_gemms
+
+    m = _cfg(1)
+    D, H, hq, hkv, inter, eps, T = m.head_dim, m.hidden_size, m.num_qo_heads, m.num_kv_heads, m.intermediate_size, m.rms_norm_eps, 256
+    g = torch.Generator().manual_seed(14)
+
+    def w(*shape, std=0.02):
+        return (torch.randn(shape, generator=g) * std).to(torch.bfloat16)
+
+    W = dict(qkv=w((hq + 2 * hkv) * D, H), o=w(H, hq * D), gate_up=w(2 * inter, H), down=w(H, inter),
+             post_norm=(1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16))
+    x = dict(qkv=(torch.randn((T, H), generator=g) * 0.7).to(torch.bfloat16), o=(torch.randn((T, hq * D), generator=g) * 0.3).to(torch.bfloat16),
+             gate_up=(torch.randn((T, H), generator=g) * 0.7).to(torch.bfloat16))
+    res = (torch.randn((T, H), generator=g) * 0.7).to(torch.bfloat16)
+    r = {k: F.linear(x[k].float(), W[k].float()).to(torch.bfloat16) for k in ("qkv", "o", "gate_up")}
+    r["act"] = ref_ops.silu_and_mul_ref(r["gate_up"])
+    x["down"] = r["act"]
+    r["down"] = F.linear(r["act"].float(), W["down"].float()).to(torch.bfloat16)
+    r["norm2"], r["res2"] = ref_ops.fused_add_rmsnorm_ref(r["o"], res, W["post_norm"], eps)
+
+    d = lambda t: t.to(dev)  # noqa: E731
+    Wd = {k: d(v) for k, v in W.items()}
+    Wd["gate_up_ilv"] = ops.interleave_gate_up(Wd["gate_up"])
+    groups = [("qkv", [Wd["qkv"]], H), ("o", [Wd["o"]], hq * D), ("gate_up", [Wd["gate_up_ilv"]], H, {"silu_interleaved": True}),
+              ("down", [Wd["down"]], inter)]
+    try:
+        report = tune_projection_gemms(groups, [T], "heuristic", torch.bfloat16, dev)
+        print("\n[14B layer, M = 256] " + "; ".join(f"{rr['name']}: {rr['kernel'][:60]} {rr['best_us']:.1f} us" for rr in report))
+        got = {k: ops.linear(d(x[k]), Wd[k]) for k in ("qkv", "o", "down")}
+        got["act"] = ops.linear_silu(d(x["gate_up"]), Wd["gate_up_ilv"])
+        # slab hand-off == reduce-then-norm at these dims (whatever plan was chosen; plain linear if none is k-sliced)
+        y, slabs = ops.linear_slabs(d(x["o"]), Wd["o"])
+        if slabs is not None:
+            y._msgl_slabs = slabs
+        r2 = d(res).clone()
+        fi.fused_add_rmsnorm(y, r2, Wd["post_norm"], eps)
+        y_ref, r_ref = got["o"].clone(), d(res).clone()
+        fi.fused_add_rmsnorm(y_ref, r_ref, Wd["post_norm"], eps)
+        assert torch.equal(y, y_ref) and torch.equal(r2, r_ref)
+        torch.cuda.synchronize()
+        lines = []
+        for name, ulps in dict(qkv=2, o=2, down=2, act=3).items():
+            st = parity_stats.logit_error_stats(got[name].float().cpu().reshape(-1), r[name].float().reshape(-1))
+            lines.append(f"{name:5s} max {st['max_ulp']:.2f} ulp  p99 {st['p99_ulp']:.2f}  mean {st['mean_ulp']:.3f}  |err| max {st['max_abs']:.2e}")
+            assert st["max_ulp"] <= ulps + 1e-6, (name, parity_stats.fmt(st))
+        print("[14B layer, each projection on the oracle's input]\n" + "\n".join(lines))
+    finally:
+        ops.reset_gemm_plans()

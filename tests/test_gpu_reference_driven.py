@@ -238,6 +238,49 @@ def test_reference_driven_radix_chunked_prefill_and_repeats_tiny(dev, model_dirs
     assert agree >= 0.9 * total
 
 
+def test_reference_driven_tp2_through_the_plugin_two_ranks_on_one_gpu(dev, model_dirs):
+    """VERDICT r2 missing 2 / next 3a: the reference's own TP path through `install()` -- `Engine._init_communication`
+    -> `enable_pynccl_distributed` -> OUR `init_pynccl(tp_rank, tp_size, tp_cpu_group, max_size_bytes)`
+    (P/distributed/impl.py:73-90), `_sync_get_memory` (P/engine/engine.py:171-190), sharded weight loading, the
+    vocab-parallel embedding + all-reduce (P/layers/embedding.py:33-42), the row-parallel projections' all-reduce
+    (P/layers/linear.py:102-106, 123-127) and the LM-head all-gather (embedding.py:102-110) -- executed by two rank
+    processes (each the reference's Scheduler + Engine + GraphRunner, sharing the box's one GPU over the peer-to-peer
+    communicator).  Checks: both ranks produce the same bits and the same tokens; logits == this repository's tp = 2
+    engine on the recorded batches, bit for bit; == the tp = 1 engine within the tolerance of the split summation."""
+    mdir, state = model_dirs("tiny")
+    g = torch.Generator().manual_seed(21)
+    shared = torch.randint(0, 1000, (40,), generator=g).tolist()
+    prompts = [shared + torch.randint(0, 1000, (n,), generator=g).tolist() for n in (7, 30, 64)] + \
+              [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (5, 100)]
+    kw = dict(page_size=4, max_running_req=8, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512, num_page_override=512,
+              max_extend_tokens=96, cache_type="radix")
+    spec = dict(model="tiny", model_dir=mdir, llm_kwargs=kw, deterministic_decode_order=True, full_logits_forwards=0,
+                replay_repo_engine=True, rounds=[dict(prompts=prompts, sampling=[greedy(6)] * len(prompts))])
+    r0, r1 = refdrive.run_tp_workers(spec, 2)
+    for r in (r0, r1):
+        assert r["backend"] == "HipAttnBackend" and r["attention_forward_fused"] and r["integrity"] == "ok"
+        assert r["comm_class"] == "HybridCommunicator" and r["comm_p2p_error"] == 0 and not r["comm_has_rccl"]
+        assert r["interleaved_mlps"] == 2   # both layers' sharded gate_up went through the fused-MLP conversion
+    assert r0["tp_rank"] == 0 and r1["tp_rank"] == 1 and r0["tp_size"] == 2
+    assert r0["outputs"] == r1["outputs"] and all(len(o) == 6 for o in r0["outputs"][0])
+    assert len(r0["forwards"]) == len(r1["forwards"])
+    assert any(any(f["chunked"]) for f in r0["forwards"]) and any(f["graph"] for f in r0["forwards"])
+    for i, (a, b) in enumerate(zip(r0["forwards"], r1["forwards"])):
+        assert a["phase"] == b["phase"] and a["uids"] == b["uids"] and torch.equal(a["out_loc"], b["out_loc"]), i
+        sa, sb = a["summary"], b["summary"]
+        assert torch.equal(sa["argmax"], sb["argmax"]) and torch.equal(sa["top2"], sb["top2"]) and \
+            torch.equal(sa["checksum"], sb["checksum"]), f"ranks disagree on the logits bits of forward {i}"
+    for r in (r0, r1):
+        rep = r["repo_replay"]
+        assert rep["comm_error"] == 0
+        assert all(rep["bit_identical"]), [i for i, ok in enumerate(rep["bit_identical"]) if not ok]
+    worst = max(r0["repo_replay"]["max_abs_vs_tp1"])
+    print(f"\n[refdrive tp2, two ranks on one GPU] {len(r0['forwards'])} forwards, ranks bit-identical, == repo tp2 engine bit for bit; "
+          f"max |logit| difference to the tp1 engine {worst:.2e}")
+    assert worst <= 2e-2
+    dump("refdrive_tp2_tiny.json", dict(forwards=len(r0["forwards"]), outputs=r0["outputs"], max_abs_vs_tp1=worst))
+
+
 def test_reference_driven_native_radix_makes_the_same_schedule(dev, model_dirs):
     """cache_type="hip_radix" (native tree walk, csrc/radix.cpp) + vectorised scheduler glue under the reference's scheduler on the GPU: the same
     prompts, greedy, produce the same batches -- cached lengths, KV block indices (out_loc, page-table rows), graph use --

@@ -66,6 +66,21 @@ def test_p2p_collectives_known_answers(dev, world):
     print(f"\n[p2p world={world}] two-shot all-reduce of 2.6 MB, all ranks on one GPU: {res[0]['two_shot_2p6MB_us']:.0f} us")
 
 
+def test_p2p_barrier_timeout_poisons_and_raises(dev):
+    """comm_p2p.hip: a barrier whose peer never arrives gives up after the spin limit; the collective's output is
+    NaN-poisoned instead of a partial sum, the error word is sticky (later collectives fail fast), and every host poll
+    (sync, async, destroy) raises MsglError.  The rank that stayed away is untouched."""
+    r0, r1 = launch("absent_rank", 2, timeout=180.0)
+    assert r0["two_shot_all_nan"] and r0["one_shot_all_nan"] and r0["gather_all_nan"], r0
+    assert r0["error_word"] != 0 and r1["error_word"] == 0
+    assert r0["raised"]["sync"] and "gave up waiting" in r0["raised"]["sync"]
+    assert r0["raised"]["async"] and "gave up waiting" in r0["raised"]["async"]
+    assert r0["destroy_raised"]
+    # the first collective spun until the limit, the later ones saw the sticky word and returned at once
+    assert r0["one_shot_seconds"] < max(0.05, 0.2 * r0["two_shot_seconds"]), r0
+    print(f"\n[p2p timeout] gave up after {r0['two_shot_seconds']:.2f} s (limit 100k polls); next collective {r0['one_shot_seconds'] * 1e3:.1f} ms")
+
+
 def test_tp2_product_forward_matches_tp1(dev):
     from mini_sglang_amd.model import PRESETS
 

@@ -7,6 +7,7 @@ that is how N > 1 execution of the product is covered on a 1-GPU box.  Modes:
   collectives   the reference's known answers (tests/kernel/test_comm.py:96-149: ones -> n^rounds, rank-valued ->
                 n(n-1)/2 with a lagging rank 0, half zeros / half ones, all-gather of rank-valued chunks) at one-shot and
                 two-shot sizes, ragged counts, bit-identity across ranks, hipGraph capture + replay
+  absent_rank   rank 0 enters collectives nobody else joins: NaN-poisoned outputs, sticky error word, polls raise
   tp_model      DenseDecoder(tp_size = n) through Engine + OfflineRunner on the tiny model: logits of every forward
                 (rank 0 also runs the tp = 1 engine on the same full weights for the parent to compare), KV shards,
                 token-split side-stream overlap on vs off
@@ -104,6 +105,64 @@ def collectives(rank: int, world: int, dev: torch.device) -> dict:
     return res
 
 
+def absent_rank(rank: int, world: int, dev: torch.device) -> dict:
+    """A peer that never arrives: rank 0 runs a collective nobody else joins.  Its barrier
+    must give up, the output must be NaN-poisoned (never a partial sum), the error word sticky, every poll form must
+    raise, and later collectives must fail fast instead of spinning again."""
+    from mini_sglang_amd._lib import MsglError
+    from mini_sglang_amd.kernel import HybridCommunicator, P2PCommunicator
+
+    res = {"world": world}
+    comm = P2PCommunicator(rank, world, dist.group.WORLD, max_bytes=4 << 20, one_shot_max_bytes=256 << 10, blocks=8)
+    comm.set_spin_limit(100_000)
+    for numel in (4096, 256 * 1024):  # a healthy round first (one-shot, two-shot)
+        x = torch.full((numel,), float(rank + 1), dtype=torch.bfloat16, device=dev)
+        comm.all_reduce(x)
+        torch.cuda.synchronize()
+        assert bool((x == float(world * (world + 1) // 2)).all())
+    comm.poll_error()            # enqueue a first async read: nothing wrong yet
+    torch.cuda.synchronize()
+    comm.poll_error()
+    dist.barrier()
+    if rank == 0:
+        for name, numel in (("two_shot", 256 * 1024), ("one_shot", 4096)):
+            x = torch.full((numel,), 1.0, dtype=torch.bfloat16, device=dev)
+            t0 = time.perf_counter()
+            comm.all_reduce(x)
+            torch.cuda.synchronize()
+            res[f"{name}_seconds"] = time.perf_counter() - t0
+            res[f"{name}_all_nan"] = bool(x.isnan().all())
+        dst = torch.zeros((world * 64, 128), dtype=torch.bfloat16, device=dev)
+        comm.all_gather(dst, torch.ones((64, 128), dtype=torch.bfloat16, device=dev))
+        torch.cuda.synchronize()
+        res["gather_all_nan"] = bool(dst.isnan().all())
+        res["error_word"] = comm.error()
+        raised = {}
+        for form in ("sync", "async"):
+            try:
+                if form == "sync":
+                    comm.poll_error(sync=True)
+                else:
+                    comm._err_event = None
+                    comm.poll_error()        # enqueues the copy
+                    torch.cuda.synchronize()
+                    comm.poll_error()        # sees it
+                raised[form] = None
+            except MsglError as e:
+                raised[form] = str(e)
+        res["raised"] = raised
+        try:
+            HybridCommunicator(comm, None).destroy()   # destroying a communicator with a pending error raises too
+            res["destroy_raised"] = False
+        except MsglError:
+            res["destroy_raised"] = True
+    dist.barrier()
+    if rank != 0:
+        res["error_word"] = comm.error()
+        comm.destroy()
+    return res
+
+
 def tp_model(rank: int, world: int, dev: torch.device) -> dict:
     import refdrive
     from mini_sglang_amd.core import SamplingParams
@@ -172,7 +231,7 @@ def main() -> None:
     rank, world, port = int(os.environ["RANK"]), int(os.environ["WORLD"]), int(os.environ["PORT"])
     torch.cuda.set_device(dev)
     dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    res = {"collectives": collectives, "tp_model": tp_model}[mode](rank, world, dev)
+    res = {"collectives": collectives, "tp_model": tp_model, "absent_rank": absent_rank}[mode](rank, world, dev)
     torch.save(res, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
