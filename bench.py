@@ -164,7 +164,18 @@ def main() -> None:
     ap.add_argument("--no-prefill-roofline", action="store_true", help="skip the prefill-attention MFMA measurement")
     ap.add_argument("--small-batches", type=int, nargs="*", default=[1, 8, 32],
                     help="also report ms per decode step at these batch sizes (latency regime; [] to skip)")
+    ap.add_argument("--rank-shard", type=int, default=0,
+                    help="N > 1: time ONE rank's shard of a TP = N decode step on this GPU with the collectives looped back "
+                         "(tools/rank_shard_bench.py): an upper bound on the TP = N speed-up before any link is paid")
+    ap.add_argument("--tp1-ms", type=float, default=None, help="with --rank-shard: the TP1 ms/step to compare against")
     args = ap.parse_args()
+    if args.rank_shard > 1:
+        from tools.rank_shard_bench import main as rank_shard_main
+
+        argv = ["--model", args.model, "--tp", str(args.rank_shard), "--batch", str(args.batch), "--steps", str(args.steps),
+                "--warmup", str(args.warmup), "--page-size", str(args.page_size)]
+        rank_shard_main(argv + (["--tp1-ms", str(args.tp1_ms)] if args.tp1_ms else []))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -439,7 +450,7 @@ def main() -> None:
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
-        engine.shutdown()
+        engine.shutdown()  # raises if a peer-to-peer barrier ever timed out (NaN-poisoned collectives)
         for c in (comm, comm_side):
             if c is not None:
                 c.destroy()
