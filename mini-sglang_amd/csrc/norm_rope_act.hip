@@ -122,6 +122,87 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(uint16_t* out, const uint1
 }
 
 // ------------------------------------------------------------------------------
+// Fused-add RMSNorm of WIDE rows (hidden sizes: more than 128 pieces): ONE ROW PER WORKGROUP, one 8-element piece per
+// thread (blockDim = pieces rounded up to whole waves, <= 1024); with slab input the slab loop is unrolled NS-fold so
+// that every load of a thread -- NS x 2 float4 of partial sums, residual, weight -- is in flight at once.
+// rmsnorm_kernel above would run such a row on 256 threads x 3 pieces with a runtime slab loop: 4 waves per CU and one
+// slab in flight per piece, 3.6 TB/s on the 39 MB a 256 x 5120 decode batch with 6 slabs moves.  EVERY fused-add norm
+// of a wide row takes this kernel, with or without slabs and at any row count, so that the slab hand-off stays
+// bit-identical to reduce-then-norm and a row's result does not depend on the batch it is in (the per-row sum of
+// squares is added in one fixed order: lanes by wave_sum, waves in index order).
+// ------------------------------------------------------------------------------
+template <typename T, int NS, bool SLABS>
+__global__ __launch_bounds__(1024) void rmsnorm_wide_row_kernel(uint16_t* x, uint16_t* residual,
+                                                                const uint16_t* __restrict__ weight, float eps, int dim,
+                                                                int64_t xs, int64_t rs, const float* __restrict__ slabs,
+                                                                int n_slabs, int64_t slab_stride, int64_t slab_ld) {
+  __shared__ float lds[16];
+  const int64_t r = blockIdx.x;
+  const int p = threadIdx.x;
+  const int pieces = dim >> 3;
+  const bool has = p < pieces;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  U4 wq = U4{0, 0, 0, 0};
+  float ss = 0.f;
+  if (has) {
+    U4 rq;
+    if constexpr (SLABS) {
+      const float* sp = slabs + r * slab_ld + p * 8;
+      float4 a[NS], b[NS];
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        const float* q = sp + (int64_t)(sl < n_slabs ? sl : 0) * slab_stride;  // clamped: loads stay unconditional
+        a[sl] = *reinterpret_cast<const float4*>(q);
+        b[sl] = *reinterpret_cast<const float4*>(q + 4);
+      }
+      rq = ldg16(residual + r * rs + p * 8);
+      wq = ldg16(weight + p * 8);
+      float4 sa = a[0], sb = b[0];
+#pragma unroll
+      for (int sl = 1; sl < NS; ++sl)
+        if (sl < n_slabs) {
+          sa.x += a[sl].x; sa.y += a[sl].y; sa.z += a[sl].z; sa.w += a[sl].w;
+          sb.x += b[sl].x; sb.y += b[sl].y; sb.z += b[sl].z; sb.w += b[sl].w;
+        }
+      for (int sl = NS; sl < n_slabs; ++sl) {  // more slabs than the unrolled part
+        const float* q = sp + (int64_t)sl * slab_stride;
+        const float4 a2 = *reinterpret_cast<const float4*>(q), b2 = *reinterpret_cast<const float4*>(q + 4);
+        sa.x += a2.x; sa.y += a2.y; sa.z += a2.z; sa.w += a2.w;
+        sb.x += b2.x; sb.y += b2.y; sb.z += b2.z; sb.w += b2.w;
+      }
+      const float f[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+      unpack8<T>(pack8<T>(f), v);  // the rounded projection output, as the reduce kernel stores it
+    } else {
+      const U4 xq = ldg16(x + r * xs + p * 8);
+      rq = ldg16(residual + r * rs + p * 8);
+      wq = ldg16(weight + p * 8);
+      unpack8<T>(xq, v);
+    }
+    float rr[8];
+    unpack8<T>(rq, rr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+    stg16(residual + r * rs + p * 8, pack8<T>(v));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+  }
+  ss = wave_sum(ss);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) lds[w] = ss;
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = 0; i < nw; ++i) tot += lds[i];
+  const float inv = rsqrtf(tot / (float)dim + eps);
+  if (has) {
+    float wv[8], y[8];
+    unpack8<T>(wq, wv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(__fmul_rn(v[e], inv), wv[e]);
+    stg16(x + r * xs + p * 8, pack8<T>(y));
+  }
+}
+
+// ------------------------------------------------------------------------------
 // NeoX RoPE in place.  One thread rotates 8 (low half) + 8 (high half) elements.
 // ------------------------------------------------------------------------------
 template <typename T, typename PosT>
@@ -299,6 +380,24 @@ static int launch_rmsnorm(uint16_t* out, const uint16_t* x, uint16_t* res, const
                           int64_t os1, int64_t rs0, hipStream_t s, const float* slabs = nullptr, int n_slabs = 0,
                           int64_t slab_stride = 0, int64_t slab_ld = 0) {
   const int pieces = (int)(dim / 8);
+  if constexpr (FUSED) {
+    if (pieces > 128 && pieces <= 1024 && n1 == 1 && x == out) {  // hidden-size rows: one row per workgroup (see the kernel)
+      const unsigned threads = (unsigned)((pieces + 63) / 64 * 64);
+      MSGL_REQUIRE(rows < (1ll << 31), "fused_add_rmsnorm: too many rows");
+      if constexpr (SLABS) {
+        if (n_slabs <= 4)
+          rmsnorm_wide_row_kernel<T, 4, true><<<dim3((unsigned)rows), dim3(threads), 0, s>>>(
+              out, res, w, eps, (int)dim, xs0, rs0, slabs, n_slabs, slab_stride, slab_ld);
+        else
+          rmsnorm_wide_row_kernel<T, 8, true><<<dim3((unsigned)rows), dim3(threads), 0, s>>>(
+              out, res, w, eps, (int)dim, xs0, rs0, slabs, n_slabs, slab_stride, slab_ld);
+      } else {
+        rmsnorm_wide_row_kernel<T, 1, false><<<dim3((unsigned)rows), dim3(threads), 0, s>>>(
+            out, res, w, eps, (int)dim, xs0, rs0, nullptr, 0, 0, 0);
+      }
+      return MSGL_OK;
+    }
+  }
 #define MSGL_NORM(TPR, KMAX)                                                                        \
   do {                                                                                              \
     const int64_t rpb = 256 / TPR;                                                                  \
