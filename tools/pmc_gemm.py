@@ -1,0 +1,107 @@
+"""Launch the M = 256 projection path of one Qwen3-14B layer, kernel by kernel, for rocprofv3 --pmc passes (VERDICT r2
+"next" 2: FETCH_SIZE, WRITE_SIZE and L2 hit counters per GEMM kernel and for the slab-consuming norm).
+
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_g_FETCH_SIZE -- python tools/pmc_gemm.py --manifest gpurun_out/pmc_gemm_manifest.json
+    python tools/pmc_gemm_summary.py <results.db> gpurun_out/pmc_gemm_manifest.json
+
+Every launch streams a different layer's weights (8 rotating buffers per shape); plans = what the pre-capture search
+picks at M = 256 (k-sliced g3 / m256 kernels leave fp32 slabs, consumed by the fused-add RMSNorm resp. the
+qk-norm/RoPE/store pass, exactly as in the captured decode step).  Three 1-GiB device copies first: the FETCH_SIZE
+calibration (gfx950 reports half of a wide streaming read).  The manifest lists the launches in order with their
+algorithmic bytes so that the summary can attribute dispatches of the same kernel name to the right projection.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from mini_sglang_amd import ops  # noqa: E402
+from mini_sglang_amd.model import PRESETS  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="qwen3-14b")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--manifest", default="gpurun_out/pmc_gemm_manifest.json")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    m, D = PRESETS[a.model], PRESETS[a.model].head_dim
+    M, H, hq, hkv, inter = a.batch, m.hidden_size, m.num_qo_heads, m.num_kv_heads, m.intermediate_size
+    bf = torch.bfloat16
+
+    def ws(n, k, count=8):
+        return [(torch.randn((n, k), device=dev) * 0.02).to(bf) for _ in range(count)]
+
+    W = dict(qkv=ws((hq + 2 * hkv) * D, H), o=ws(H, hq * D), gate_up=ws(2 * inter, H, 4), down=ws(H, inter, 4))
+    N = dict(qkv=(hq + 2 * hkv) * D, o=H, gate_up=2 * inter, down=H)
+    K = dict(qkv=H, o=hq * D, gate_up=H, down=inter)
+    # FIXED plans (a timing search under the profiler picks different kernels in every pass): what the search picks
+    # un-profiled on this model -- k-sliced g3 for qkv / o / down, the library for gate_up -- plus the hand-written
+    # gate_up variants the search rejects, for comparison
+    dt = ops._dt(torch.empty(0, dtype=bf))
+    for name, split in (("qkv", 4), ("o", 6), ("down", 6)):
+        ops._M256_PLAN[(0, M, N[name], K[name], K[name], K[name], dt)] = (256, 0, split, 1)
+    x = {k: torch.randn((M, v), device=dev).to(bf) for k, v in K.items()}
+    res = torch.randn((M, H), device=dev).to(bf)
+    nw = torch.ones(H, device=dev, dtype=bf)
+    qw = torch.ones(D, device=dev, dtype=bf)
+    pos = torch.arange(M, device=dev, dtype=torch.int32)
+    cos_sin = torch.randn((4096, D), device=dev)
+    kc = torch.zeros((1024, hkv * D), device=dev, dtype=bf)
+    vc = torch.zeros_like(kc)
+    loc = torch.arange(M, device=dev, dtype=torch.int32)
+    wi = [ops.interleave_gate_up(w) for w in W["gate_up"]]
+    half = torch.empty((M, inter), device=dev, dtype=bf)
+    # warm every path once (code objects, library heuristics) before the measured region
+    ops.silu_and_mul(ops.linear(x["gate_up"], W["gate_up"][0]))
+    ops.g3_linear(x["gate_up"], wi[0], 256, 256, 16, out=half, silu=True)
+    ops.g3_linear(x["gate_up"], wi[0], 256, 256, 16)
+    torch.cuda.synchronize()
+    a1 = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    b1 = torch.empty_like(a1)
+    for _ in range(3):
+        b1.copy_(a1)
+    torch.cuda.synchronize()
+    expected = []
+
+    def algo(n, k):
+        return 2 * n * k + 2 * M * k + 2 * M * n
+
+    for rep in range(a.reps):
+        w = W["qkv"][rep % len(W["qkv"])]
+        qkv, slabs = ops.linear_slabs(x["qkv"], w)
+        ops.qk_norm_rope_store_slabs(qkv, slabs, hq, hkv, qw, qw, 1e-6, pos, cos_sin, kc, vc, loc, D)
+        expected += [("qkv g3 4 k-slices (slabs)", "gemm"), ("qk-norm/RoPE/store reading 4 slabs", "qk")]
+        w = W["o"][rep % len(W["o"])]
+        y, slabs = ops.linear_slabs(x["o"], w)
+        ops.fused_add_rmsnorm_slabs(y, res, nw, 1e-6, slabs)
+        expected += [("o g3 6 k-slices (slabs)", "gemm"), ("fused-add RMSNorm reading 6 slabs", "norm")]
+        w = W["gate_up"][rep % len(W["gate_up"])]
+        act = ops.silu_and_mul(ops.linear(x["gate_up"], w))
+        expected += [("gate_up library (heuristic solution)", "gemm"), ("SiLU.mul", "silu")]
+        w = W["down"][rep % len(W["down"])]
+        y, slabs = ops.linear_slabs(act, w)
+        ops.fused_add_rmsnorm_slabs(y, res, nw, 1e-6, slabs)
+        expected += [("down g3 6 k-slices (slabs)", "gemm"), ("fused-add RMSNorm reading 6 slabs (after down)", "norm")]
+        ops.g3_linear(x["gate_up"], wi[rep % len(wi)], 256, 256, 16, out=half, silu=True)
+        expected += [("gate_up g3 fused SiLU.mul 256 whole + 16 tail tiles x 16 slices", "gemm"), ("tail reduce + SiLU.mul", "reduce")]
+    torch.cuda.synchronize()
+    sizes = {"qkv": algo(N["qkv"], K["qkv"]), "o": algo(N["o"], K["o"]), "gate_up": algo(N["gate_up"], K["gate_up"]),
+             "down": algo(N["down"], K["down"])}
+    manifest = dict(reps=a.reps, expected=expected, algorithmic_bytes=sizes,
+                    weight_bytes={k: 2 * N[k] * K[k] for k in N}, x_bytes={k: 2 * M * K[k] for k in K},
+                    norm_algorithmic_bytes=4 * M * H * 2, silu_algorithmic_bytes=3 * M * inter * 2)
+    Path(a.manifest).parent.mkdir(parents=True, exist_ok=True)
+    Path(a.manifest).write_text(json.dumps(manifest, indent=1))
+
+
+if __name__ == "__main__":
+    main()
