@@ -410,6 +410,7 @@ def main() -> None:
                             "fused_silu_epilogue_us": round(r["silu_fused_us"], 1), "fused_silu_used": r["silu_fused_used"]}
                            if r.get("silu_fused_us") else {})) for r in engine.gemm_report],
     }
+    result["gemm_tune"]["refined_in_graph"] = getattr(engine, "refine_report", [])
     # what the REFERENCE's own LLM / Scheduler / GraphRunner measure on this path through the plugin: recorded by
     # tests/test_gpu_reference_driven.py (it may import oracle/_ref, this file may not) and committed under profiles/
     ref_runs = sorted((ROOT / "profiles").glob("r*_refdrive_14b.json"))

@@ -429,6 +429,11 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
                    int* n_tried, void* stream);
 /* kernel name of the remembered solution into buf; returns its library index (< 0 on error) */
 int msgl_gemm_reset_plans(void);  /* forget all plans: shapes fall back to the library heuristic */
+/* The best few candidates of the shape's last msgl_gemm_tune, fastest first (count returned, times in us_out), and the
+ * switch that makes one of them the shape's plan: back-to-back timing separates the top library solutions by ~1 %,
+ * inside a captured decode step they differ by up to 9 %, so the host re-ranks them in the step itself. */
+int msgl_gemm_finalists(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, float* us_out, int max_n);
+int msgl_gemm_select_finalist(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int index);
 int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype,
                             char* buf, int buf_len);
 const char* msgl_gemm_last_error(void);

@@ -104,6 +104,10 @@ struct Plan {
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;  // per device
 std::map<Key, Plan> g_plans;
+// the best few candidates of the last search per shape, fastest first (msgl_gemm_finalists / msgl_gemm_select_finalist):
+// back-to-back timing separates the top solutions by ~1 %, inside a captured decode step they differ by up to 9 %, so the
+// host re-ranks them in place (engine.Engine.refine_plans_in_graph)
+std::map<Key, std::vector<std::pair<float, Plan>>> g_finalists;
 // Untuned (heuristic) plans are created on first use of a shape; prefill M = total extend tokens takes almost any
 // value, so a long-running server would grow the map without bound.  Tuned plans (decode shapes, a few dozen) are
 // kept; untuned ones are dropped oldest-first beyond this many.
@@ -414,6 +418,18 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   chosen.tuned = true;
   const Key key{dev, M, N, K, ldx, ldw, ldo, dtype};
   g_plans[key] = chosen;  // base.prob stays alive (shared by the map entry)
+  {
+    std::vector<std::pair<float, Plan>> fl;
+    for (int r = 0; r < finals; ++r)
+      if (fin[r] < 1e29f) {
+        Plan c = cands[ranked[r].second];
+        c.tuned = true;
+        fl.emplace_back(fin[r], c);
+      }
+    std::sort(fl.begin(), fl.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    if (fl.size() > 6) fl.resize(6);
+    g_finalists[key] = fl;
+  }
   if (best_us) *best_us = best;
   if (default_us) *default_us = def;
   if (best_index) *best_index = chosen.algo_index;
@@ -430,7 +446,38 @@ int msgl_gemm_reset_plans(void) {
   for (auto& kv : g_plans)
     if (!kv.second.tuned) release_plan(kv.second);
   g_plans.clear();
+  g_finalists.clear();
   g_untuned_order.clear();
+  return MSGL_OK;
+}
+
+// The best candidates of the last msgl_gemm_tune of this shape, fastest first: writes up to max_n times (us) and returns
+// how many there are (0 if the shape was never searched).
+int msgl_gemm_finalists(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, float* us_out, int max_n) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  int rc = get_handle(&h, &dev);
+  if (rc != MSGL_OK) return rc;
+  auto it = g_finalists.find(Key{dev, M, N, K, ldx, ldw, ldo, dtype});
+  if (it == g_finalists.end()) return 0;
+  const int n = (int)it->second.size();
+  for (int i = 0; i < n && i < max_n && us_out; ++i) us_out[i] = it->second[(size_t)i].first;
+  return n;
+}
+
+// Make finalist `index` the shape's plan (what msgl_gemm_nt launches from now on).
+int msgl_gemm_select_finalist(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int index) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  int rc = get_handle(&h, &dev);
+  if (rc != MSGL_OK) return rc;
+  const Key key{dev, M, N, K, ldx, ldw, ldo, dtype};
+  auto it = g_finalists.find(key);
+  GEMM_REQUIRE(it != g_finalists.end() && index >= 0 && index < (int)it->second.size(),
+               "gemm_select_finalist: shape has no finalist %d", index);
+  g_plans[key] = it->second[(size_t)index].second;
   return MSGL_OK;
 }
 

@@ -7,6 +7,8 @@ GPU box, where only this repository is present.
 """
 from __future__ import annotations
 
+import os
+
 import gc
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, NamedTuple, Optional
@@ -92,6 +94,7 @@ class EngineConfig:
     comm_overlap: bool = True
     tp_cpu_group: Any = None  # torch.distributed CPU group of the TP ranks (pool sizing agreement)
     gemm_tune: str = "heuristic"  # "off" | "heuristic" | "full": library solution search per graph batch size
+    refine_in_graph: bool = True  # re-rank the search's finalists at the largest graph batch inside the captured step
     seed: int = 42
 
     @property
@@ -154,23 +157,28 @@ class GraphRunner:
         backend = engine.attn_backend
         backend.init_capture_graph(max_seq_len=engine.aligned_max_seq_len, bs_list=self.graph_bs_list)
         torch.cuda.synchronize(dev)
-        pool = None
+        self._pool = None
         for bs in sorted(self.graph_bs_list, reverse=True):
-            graph = torch.cuda.CUDAGraph()
-            batch = Batch(reqs=[engine.dummy_req] * bs, phase="decode")
-            batch.padded_reqs = batch.reqs
-            backend.prepare_for_capture(batch)
-            batch.input_ids, batch.out_loc, batch.positions = self.input_ids[:bs], self.out_loc[:bs], self.positions[:bs]
-            with engine.ctx.forward_batch(batch):
+            self.capture(bs)
+
+    def capture(self, bs: int) -> None:
+        """(Re)capture the decode forward at batch size `bs` with the kernel plans in force now."""
+        engine, backend = self.engine, self.engine.attn_backend
+        graph = torch.cuda.CUDAGraph()
+        batch = Batch(reqs=[engine.dummy_req] * bs, phase="decode")
+        batch.padded_reqs = batch.reqs
+        backend.prepare_for_capture(batch)
+        batch.input_ids, batch.out_loc, batch.positions = self.input_ids[:bs], self.out_loc[:bs], self.positions[:bs]
+        with engine.ctx.forward_batch(batch):
+            self.logits[:bs] = engine.model.forward(engine.ctx, batch)
+            # with a communicator inside the graph, RCCL's proxy thread may touch the HIP API while this
+            # thread captures: only this thread's calls are held to the capture rules then
+            mode = "thread_local" if engine.cfg.tp_size > 1 else "global"
+            with torch.cuda.graph(graph, pool=self._pool, stream=engine.stream, capture_error_mode=mode):
                 self.logits[:bs] = engine.model.forward(engine.ctx, batch)
-                # with a communicator inside the graph, RCCL's proxy thread may touch the HIP API while this
-                # thread captures: only this thread's calls are held to the capture rules then
-                mode = "thread_local" if engine.cfg.tp_size > 1 else "global"
-                with torch.cuda.graph(graph, pool=pool, stream=engine.stream, capture_error_mode=mode):
-                    self.logits[:bs] = engine.model.forward(engine.ctx, batch)
-            if pool is None:
-                pool = graph.pool()
-            self.graph_map[bs] = graph
+        if self._pool is None:
+            self._pool = graph.pool()
+        self.graph_map[bs] = graph
 
     def can_use_cuda_graph(self, batch: Batch) -> bool:
         return batch.is_decode and batch.size <= self.max_graph_bs
@@ -238,6 +246,10 @@ class Engine:
         # solution search happens before capture (it synchronises); full search only where it pays
         self.gemm_report = self.model.tune_gemms(bs_list, cfg.gemm_tune)
         self.graph_runner = GraphRunner(self, bs_list)
+        self.refine_report: List[dict] = []
+        if cfg.refine_in_graph and cfg.gemm_tune != "off" and bs_list and cfg.tp_size == 1 and \
+                os.environ.get("MSGL_DISABLE_REFINE") != "1":
+            self.refine_report = self.refine_plans_in_graph(max(bs_list))
         if cfg.tp_size > 1 and cfg.tp_cpu_group is not None:
             # kernel search and capture take a rank-dependent time; the device-side barriers of the peer-to-peer
             # collectives spin for a bounded time only, so the ranks meet on the CPU before the first forward
@@ -245,6 +257,20 @@ class Engine:
 
             torch.cuda.synchronize(self.device)
             dist.barrier(group=cfg.tp_cpu_group)
+
+    def refine_plans_in_graph(self, bs: int) -> List[dict]:
+        """Re-rank the search's finalists inside the captured decode step (plan_refine.refine_plans_in_graph); tp = 1
+        only: every replay runs the collectives, so the ranks would have to agree on the number of replays."""
+        from .plan_refine import refine_plans_in_graph
+
+        gr = self.graph_runner
+        if bs not in gr.graph_map:
+            return []
+        return refine_plans_in_graph(
+            bs=bs, page_table=self.page_table, page_size=self.cfg.page_size, num_pages=self.num_pages,
+            row_len=self.aligned_max_seq_len, device=self.device, Req=Req, Batch=Batch,
+            prepare_metadata=self.attn_backend.prepare_metadata, capture=lambda: gr.capture(bs), replay=gr.replay,
+            forward_ctx=self.ctx.forward_batch)
 
     def _agreed_free_memory(self, free: int) -> int:
         """Every TP rank must derive the same num_pages / max_seq_len / page-table width (the schedulers are

@@ -77,6 +77,7 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r["best_us"] = fr["fused_us"]  # projection AND activation
                     r["skinny_used"] = True
                     r["kernel"] = "msgl::g3_gemm_kernel<silu>[grid %d, whole tiles %d, k-slices %d]" % tuple(fr["plan"])
+            ops.register_candidates(name, x, ws[0], r)
             report.append(r)
             if log is not None:
                 log(f"[gemm_tune] bs={bs} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us "

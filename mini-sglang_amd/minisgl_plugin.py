@@ -329,6 +329,41 @@ def _deferred_reduce_weights(model: Any) -> set:
     return ptrs
 
 
+def _refine_reference_graphs(gr: Any, model: Any) -> List[dict]:
+    """plan_refine.refine_plans_in_graph on the reference's GraphRunner: the finalists of the pre-capture search are
+    re-ranked inside the reference's own captured decode graph of the largest batch size.  `capture` below restates
+    the body of the reference's capture loop for ONE size (P/engine/graph.py:130-145) on the reference's objects."""
+    import torch
+
+    from minisgl.core import Batch, Req, get_global_ctx
+
+    from .plan_refine import refine_plans_in_graph
+
+    ctx, bs = get_global_ctx(), gr.max_graph_bs
+    if bs not in gr.graph_map:
+        return []
+
+    def capture() -> None:
+        pool = gr.graph_map[bs].pool()
+        graph = torch.cuda.CUDAGraph()
+        batch = Batch(reqs=[gr.dummy_req] * bs, phase="decode")
+        batch.padded_reqs = batch.reqs
+        gr.attn_backend.prepare_for_capture(batch)
+        gr.buffer.set_batch(batch)
+        with ctx.forward_batch(batch):
+            gr.buffer.logits[:bs] = model.forward()
+            with torch.cuda.graph(graph, pool=pool, stream=gr.stream):
+                gr.buffer.logits[:bs] = model.forward()
+        gr.graph_map[bs] = graph
+
+    k0 = ctx.kv_cache.k_cache(0)
+    return refine_plans_in_graph(
+        bs=bs, page_table=ctx.page_table, page_size=ctx.page_size, num_pages=int(k0.shape[0]) - 1,
+        row_len=int(ctx.page_table.shape[1]), device=gr.device, Req=Req, Batch=Batch,
+        prepare_metadata=gr.attn_backend.prepare_metadata, capture=capture, replay=gr.replay,
+        forward_ctx=ctx.forward_batch)
+
+
 def _install_tune_before_capture() -> None:
     from minisgl.engine.graph import GraphRunner
 
@@ -357,9 +392,12 @@ def _install_tune_before_capture() -> None:
         if _STATE["fast_linear"] and os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1":
             _STATE["deferred_reduce_weights"] = _deferred_reduce_weights(model)
         out = reference_capture(self, max_seq_len, vocab_size, model)
+        world = 1
         try:
             import torch
             import torch.distributed as dist
+
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 # kernel search and capture take a rank-dependent time, and the device-side barriers of the peer-to-peer
@@ -369,6 +407,9 @@ def _install_tune_before_capture() -> None:
                 dist.barrier()
         except ImportError:
             pass
+        if (mode != "off" and self.max_graph_bs > 0 and _STATE["fast_linear"] and world == 1
+                and os.environ.get("MSGL_DISABLE_REFINE") != "1"):
+            _STATE["refine_report"] = _refine_reference_graphs(self, model)
         return out
 
     _capture_graphs._msgl_tuned = True  # type: ignore[attr-defined]

@@ -843,6 +843,92 @@ def linear_slabs(x: torch.Tensor, w: torch.Tensor):
     return linear(x, w), None
 
 
+# ---- candidates for re-ranking inside the captured step (engine.Engine.refine_plans_in_graph)
+_CANDIDATES: dict = {}  # plan key -> {"name": str, "cands": [(label, spec), ...]}; spec: ("lib", i) | ("hand", plan4) | ("fused", plan3)
+
+
+def plan_key(x: torch.Tensor, w: torch.Tensor):
+    return (x.device.index or 0, x.shape[0], w.shape[0], x.shape[1], x.stride(0), w.stride(0), _dt(x))
+
+
+def gemm_finalists(x: torch.Tensor, w: torch.Tensor, out_ld: Optional[int] = None) -> list:
+    """Times (us, back to back) of the best library candidates of the last gemm_tune of this shape, fastest first."""
+    import ctypes as C
+
+    M, K = x.shape
+    N = w.shape[0]
+    buf = (C.c_float * 8)()
+    n = _lib.gemm_lib().msgl_gemm_finalists(M, N, K, x.stride(0), w.stride(0), out_ld or N, _dt(x), buf, 8)
+    _lib.check_gemm(n, "gemm_finalists")
+    return [float(buf[i]) for i in range(min(n, 8))]
+
+
+def register_candidates(name: str, x: torch.Tensor, w: torch.Tensor, report: dict) -> None:
+    """After the back-to-back search of one (batch size, projection): remember the few best of every kind for the
+    in-graph re-ranking.  Only full-batch shapes (the kinds differ by several percent there)."""
+    key = plan_key(x, w)
+    M = x.shape[0]
+    if M < M256_MIN_M:
+        return
+    cands = []
+    for i, us in enumerate(gemm_finalists(x, w)[:3]):
+        cands.append((f"library #{i} ({us:.1f} us)", ("lib", i)))
+    allp = report.get("m256_all") or {}
+    for lab, us in sorted(allp.items(), key=lambda kv: kv[1])[:2]:
+        plan = tuple(int(v) for v in lab.split("/"))
+        cands.append((f"{('m256', 'g3')[plan[3]]} {plan[:3]} ({us:.1f} us)", ("hand", plan)))
+    for lab, us in sorted((report.get("silu_fused_all") or {}).items(), key=lambda kv: kv[1])[:2]:
+        cands.append((f"g3 fused SiLU.mul {lab} ({us:.1f} us)", ("fused", tuple(int(v) for v in lab.split("/")))))
+    _CANDIDATES[key] = dict(name=name, cands=cands, out_ld=w.shape[0])
+
+
+def current_candidate(key) -> str:
+    if key in _FUSED_SILU_PLAN:
+        return f"g3 fused SiLU.mul {_FUSED_SILU_PLAN[key]}"
+    if key in _M256_PLAN:
+        p = _M256_PLAN[key]
+        return f"{('m256', 'g3')[p[3] if len(p) > 3 else 0]} {tuple(p[:3])}"
+    return "library (search's pick)"
+
+
+def apply_candidate(key, spec) -> None:
+    """Make `spec` the plan of the shape `key` (see _CANDIDATES)."""
+    kind, arg = spec
+    dev, M, N, K, ldx, ldw, dt = key
+    if kind == "lib":
+        _M256_PLAN.pop(key, None)
+        _WSTREAM_PLAN.pop(key, None)
+        _FUSED_SILU_PLAN.pop(key, None)
+        _lib.check_gemm(_lib.gemm_lib().msgl_gemm_select_finalist(M, N, K, ldx, ldw, _CANDIDATES[key]["out_ld"], dt, int(arg)),
+                        "gemm_select_finalist")
+    elif kind == "hand":
+        _FUSED_SILU_PLAN.pop(key, None)
+        _M256_PLAN[key] = tuple(arg)
+    elif kind == "fused":
+        _FUSED_SILU_PLAN[key] = tuple(arg)
+    else:
+        raise ValueError(spec)
+
+
+def snapshot_plan(key):
+    """Opaque state of the shape's hand-written plans (the library's pick is restored by index 0 of its finalists)."""
+    return (_M256_PLAN.get(key), _WSTREAM_PLAN.get(key), _FUSED_SILU_PLAN.get(key))
+
+
+def restore_search_pick(key, snap) -> None:
+    """Back to what the back-to-back search left for the shape: its hand-written plans (`snap`) and, on the library
+    side, the fastest finalist (= the search's own pick: the finalists are sorted by its times)."""
+    for d, v in zip((_M256_PLAN, _WSTREAM_PLAN, _FUSED_SILU_PLAN), snap):
+        if v is None:
+            d.pop(key, None)
+        else:
+            d[key] = v
+    if any(spec[0] == "lib" for _l, spec in _CANDIDATES.get(key, {}).get("cands", [])):
+        dev, M, N, K, ldx, ldw, dt = key
+        _lib.check_gemm(_lib.gemm_lib().msgl_gemm_select_finalist(M, N, K, ldx, ldw, _CANDIDATES[key]["out_ld"], dt, 0),
+                        "gemm_select_finalist")
+
+
 def reset_gemm_plans() -> None:
     """Drop every per-shape kernel choice made so far in this process (hand-written kernel plans and library
     solutions): `linear` is the library's heuristic again until the next search."""
@@ -850,6 +936,7 @@ def reset_gemm_plans() -> None:
     _WSTREAM_PLAN.clear()
     _M256_PLAN.clear()
     _FUSED_SILU_PLAN.clear()
+    _CANDIDATES.clear()
     _PENDING_SLABS.clear()
     _lib.check_gemm(_lib.gemm_lib().msgl_gemm_reset_plans(), "gemm_reset_plans")
 

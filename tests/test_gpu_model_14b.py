@@ -34,7 +34,7 @@ def test_qwen3_14b_dims_full_decode_batch_with_tuned_plans_vs_oracle(dev):
     layers, B = 4, 256
     m = _cfg(layers)
     cfg = EngineConfig(model=m, dtype=torch.bfloat16, max_running_req=B, page_size=256, cuda_graph_bs=[B],
-                       max_seq_len_override=512, num_page_override=B + 8, seed=42, gemm_tune="heuristic")
+                       max_seq_len_override=2048, num_page_override=8 * B, seed=42, gemm_tune="heuristic")
     eng = Engine(cfg, dev)
     try:
         eng.kv_cache._kv_buffer.zero_()
@@ -42,9 +42,10 @@ def test_qwen3_14b_dims_full_decode_batch_with_tuned_plans_vs_oracle(dev):
         chosen = {k: r["kernel"][:70] for k, r in plans.items()}
         print(f"\n[14B dims] kernels at M = {B}: {chosen}")
         # the point of this test: the hand-written full-batch plans (not the library heuristic) carry the decode batch
-        sliced = [k for k in ("qkv", "o", "down") if ops._M256_PLAN and plans[k].get("m256_used")
-                  and plans[k]["m256_plan"][1] == 0 and plans[k]["m256_plan"][2] > 1]
-        assert len(sliced) >= 2, f"expected k-sliced full-batch plans for the small projections, got {chosen}"
+        print("[14B dims] after the in-graph re-ranking: " + "; ".join(f"{r['name']}: {r['chosen']}" for r in eng.refine_report))
+        assert eng.refine_report, "the in-graph re-ranking did not run (pool too small for its synthetic batch?)"
+        sliced = [k for k, p in ops._M256_PLAN.items() if k[1] == B and p[1] == 0 and p[2] > 1]
+        assert len(sliced) >= 1, f"expected a k-sliced full-batch plan (slab hand-off) among the projections, got {chosen}"
         rnd = random.Random(0)
         prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(1, 8))] for _ in range(B)]
         runner = OfflineRunner(eng, max_extend_tokens=1024, seed=1)
