@@ -153,7 +153,11 @@ class GraphRunner:
         self.input_ids = torch.zeros(self.max_graph_bs, dtype=torch.int32, device=dev)
         self.out_loc = torch.zeros(self.max_graph_bs, dtype=torch.int32, device=dev)
         self.positions = torch.zeros(self.max_graph_bs, dtype=torch.int32, device=dev)
-        self.logits = torch.empty((self.max_graph_bs, V), dtype=torch.float32, device=dev)  # graph.py:33
+        # The reference copies the model's logits into a static fp32 buffer inside the graph (P/engine/graph.py:33,
+        # 139-141).  Here the LM-head projection writes straight into the static buffer, which stays in the model dtype
+        # (the sampling kernels read it directly): no 78-MB conversion pass per step, half the bytes for the sampler;
+        # the VALUES are the same.
+        self.logits = torch.empty((self.max_graph_bs, V), dtype=engine.dtype, device=dev)
         backend = engine.attn_backend
         backend.init_capture_graph(max_seq_len=engine.aligned_max_seq_len, bs_list=self.graph_bs_list)
         torch.cuda.synchronize(dev)
@@ -170,12 +174,12 @@ class GraphRunner:
         backend.prepare_for_capture(batch)
         batch.input_ids, batch.out_loc, batch.positions = self.input_ids[:bs], self.out_loc[:bs], self.positions[:bs]
         with engine.ctx.forward_batch(batch):
-            self.logits[:bs] = engine.model.forward(engine.ctx, batch)
+            engine.model.forward(engine.ctx, batch, logits_out=self.logits[:bs])
             # with a communicator inside the graph, RCCL's proxy thread may touch the HIP API while this
             # thread captures: only this thread's calls are held to the capture rules then
             mode = "thread_local" if engine.cfg.tp_size > 1 else "global"
             with torch.cuda.graph(graph, pool=self._pool, stream=engine.stream, capture_error_mode=mode):
-                self.logits[:bs] = engine.model.forward(engine.ctx, batch)
+                engine.model.forward(engine.ctx, batch, logits_out=self.logits[:bs])
         if self._pool is None:
             self._pool = graph.pool()
         self.graph_map[bs] = graph

@@ -288,8 +288,9 @@ class DenseDecoder:
         return y
 
     # ------------------------------------------------------------------ forward
-    def forward(self, ctx: Any, batch: Any) -> torch.Tensor:
-        """P/models/qwen3.py:77-81 -> logits [B, vocab] (model dtype)."""
+    def forward(self, ctx: Any, batch: Any, logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """P/models/qwen3.py:77-81 -> logits [B, vocab] (model dtype); written into `logits_out` (rows x vocab, model
+        dtype) when given -- the graph runner's static buffer."""
         cfg, D = self.cfg, self.cfg.head_dim
         backend, kv = ctx.attn_backend, ctx.kv_cache
         x = ops.embedding_gather(self.embed, batch.input_ids,
@@ -335,7 +336,13 @@ class DenseDecoder:
         bs = batch.size
         if batch.is_prefill:
             x = x[batch.attn_metadata.get_last_indices(bs)].contiguous()
-        logits = ops.linear(x, self.lm_head)
         if self.tp_size == 1:
-            return logits
-        return lm_head_unshard(self.comm.all_gather(logits), self.tp_size, logits.shape[0], cfg.vocab_size)
+            if logits_out is not None and logits_out.shape == (x.shape[0], self.lm_head.shape[0]):
+                return ops.linear(x, self.lm_head, out=logits_out)
+            return ops.linear(x, self.lm_head)
+        logits = ops.linear(x, self.lm_head)
+        full = lm_head_unshard(self.comm.all_gather(logits), self.tp_size, logits.shape[0], cfg.vocab_size)
+        if logits_out is not None:
+            logits_out.copy_(full)
+            return logits_out
+        return full
