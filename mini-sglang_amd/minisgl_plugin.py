@@ -417,7 +417,7 @@ def _install_tune_before_capture() -> None:
 
 
 # ------------------------------------------------------------------------------ deterministic decode order (opt-in)
-def _install_deterministic_decode_order() -> None:
+def _install_deterministic_decode_order(only_under_tp: bool = False) -> None:
     """`DecodeManager.running_reqs` is a `set` of eq=False dataclasses (P/scheduler/decode.py:12,35, P/core.py:28): the
     decode batch order -- and with it the order `allocate_paged` hands out free pages (P/scheduler/cache.py:42-53) -- is
     the set's iteration order, i.e. object addresses.  Opt-in: schedule decode batches in uid order, so that two runs
@@ -426,12 +426,25 @@ def _install_deterministic_decode_order() -> None:
     from minisgl.scheduler.decode import DecodeManager
 
     if getattr(DecodeManager.schedule_next_batch, "_msgl_sorted", False):
+        if not only_under_tp:
+            DecodeManager.schedule_next_batch._msgl_always = True  # type: ignore[attr-defined]
         return
+    reference_schedule = DecodeManager.schedule_next_batch
 
     def schedule_next_batch(self):
+        if not schedule_next_batch._msgl_always:
+            try:
+                from minisgl.distributed import get_tp_info
+
+                if get_tp_info().size == 1:
+                    return reference_schedule(self)
+            except Exception:
+                return reference_schedule(self)
         if not self.runnable:
             return None
         return Batch(reqs=sorted(self.running_reqs, key=lambda r: r.uid), phase="decode")
+
+    schedule_next_batch._msgl_always = not only_under_tp  # type: ignore[attr-defined]
 
     schedule_next_batch._msgl_sorted = True  # type: ignore[attr-defined]
     DecodeManager.schedule_next_batch = schedule_next_batch
@@ -486,13 +499,20 @@ def gemm_report() -> List[dict]:
 
 
 def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True, fused_mlp: bool = True,
-            gemm_tune: Optional[str] = None, deterministic_decode_order: bool = False, native_radix: bool = False,
-            vectorized_glue: bool = False) -> None:
+            gemm_tune: Optional[str] = None, deterministic_decode_order: Optional[bool] = None, native_radix: bool = True,
+            vectorized_glue: bool = True) -> None:
     """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic").
     fused_mlp: gate_up_proj + silu_and_mul of the dense GatedMLP as ops.linear_silu (weights interleaved once, in place).
-    deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices).
-    native_radix: cache_type="radix" uses the native tree walk too (cache_type="hip_radix" always does).
-    vectorized_glue: the scheduler's per-step index tensors (positions, input / write tuples) by numpy over the whole batch."""
+    deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices);
+        None (default) = only under tensor parallelism, where the replicated schedulers of the ranks MUST build the same
+        batch (the reference's order is the iteration order of a set of id-hashed objects, i.e. heap addresses).
+    native_radix (default on): cache_type="radix" uses the native tree walk too (cache_type="hip_radix" always does);
+        same matches, inserts, evictions and free lists as the reference's tree (tests/test_cpu_native_radix.py).
+    vectorized_glue (default on): the scheduler's per-step index tensors (positions, input / write tuples) by numpy over
+        the whole batch; the same tensors as the reference's functions (tests/test_cpu_reference_native.py).
+    Measured through the reference's scheduler on the README offline benchmark at Qwen3-0.6B dims
+    (profiles/r03_refdrive_0p6b_host.json): host time in _schedule_next_batch 350 -> 202 us per iteration; with overlap
+    scheduling on the step is GPU-bound either way (4.65 ms, +0.4 % throughput), with it off +4 %."""
     if stub_zmq:
         _stub_zmq()
     _install_flashinfer_shim()
@@ -528,8 +548,8 @@ def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention:
         _install_fused_attention()
     if fused_mlp and fast_linear:
         _install_fused_gated_mlp()
-    if deterministic_decode_order:
-        _install_deterministic_decode_order()
+    if deterministic_decode_order is None or deterministic_decode_order:
+        _install_deterministic_decode_order(only_under_tp=deterministic_decode_order is None)
     _install_native_radix(replace_radix=native_radix)
     if vectorized_glue:
         _install_vectorized_glue()

@@ -107,7 +107,7 @@ def main() -> None:
     plugin.install(fast_linear=spec.get("fast_linear", True), fused_attention=spec.get("fused_attention", True),
                    gemm_tune=spec.get("gemm_tune", "off"),
                    deterministic_decode_order=spec.get("deterministic_decode_order", False),
-                   vectorized_glue=spec.get("vectorized_glue", False))
+                   vectorized_glue=spec.get("vectorized_glue", False), native_radix=spec.get("native_radix", False))
     import torch
 
     from refdrive import write_model_dir
@@ -209,6 +209,33 @@ def main() -> None:
         engine.forward_batch = forward_batch
         engine.sampler.sample = sample
 
+    # host time of the scheduler's three phases per loop iteration (P/scheduler/scheduler.py:83-119): what the backend's
+    # host side (prepare_metadata, the glue tensors, the radix cache) costs next to the GPU step
+    host = dict(schedule_s=0.0, forward_s=0.0, process_s=0.0, iterations=0)
+    if spec.get("host_timing"):
+        o_sched, o_fwd, o_proc = llm._schedule_next_batch, llm._forward, llm._process_last_data
+
+        def t_sched():
+            t = time.perf_counter()
+            r = o_sched()
+            host["schedule_s"] += time.perf_counter() - t
+            host["iterations"] += r is not None
+            return r
+
+        def t_fwd(fi_):
+            t = time.perf_counter()
+            r = o_fwd(fi_)
+            host["forward_s"] += time.perf_counter() - t
+            return r
+
+        def t_proc(ld):
+            t = time.perf_counter()
+            r = o_proc(ld)
+            host["process_s"] += time.perf_counter() - t
+            return r
+
+        llm._schedule_next_batch, llm._forward, llm._process_last_data = t_sched, t_fwd, t_proc
+
     outputs, walls = [], []
     for ri, rnd in enumerate(spec["rounds"]):
         state["round"] = ri
@@ -230,12 +257,12 @@ def main() -> None:
                 f[k] = v.cpu()
 
     cm = llm.cache_manager
-    rec = dict(spec=spec, outputs=outputs, walls=walls, forwards=forwards, init_s=init_s,
+    rec = dict(spec=spec, outputs=outputs, walls=walls, forwards=forwards, init_s=init_s, host=host,
                num_pages=engine.num_pages, max_seq_len=engine.max_seq_len, page_table_shape=tuple(engine.page_table.shape),
                graph_bs=list(engine.graph_runner.graph_bs_list), backend=type(engine.attn_backend).__name__,
                attention_forward_fused=bool(getattr(type(engine.model.model.layers.op_list[0].self_attn.attn).forward,
                                                     "_msgl_fused", False)),
-               gemm_report=plugin.gemm_report(), prefix_cache=type(cm.prefix_cache).__name__, deferred_reduce_weights=len(plugin._STATE["deferred_reduce_weights"]), free_pages_end=int(len(cm.free_slots)),
+               gemm_report=plugin.gemm_report(), refine_report=plugin._STATE.get("refine_report", []), prefix_cache=type(cm.prefix_cache).__name__, deferred_reduce_weights=len(plugin._STATE["deferred_reduce_weights"]), free_pages_end=int(len(cm.free_slots)),
                evictable_end=int(cm.prefix_cache.size_info.evictable_size), device=torch.cuda.get_device_name(0))
     rec["tp_rank"], rec["tp_size"] = tp_rank, tp_size
     if tp_size > 1:

@@ -27,7 +27,7 @@ def run(code: str, timeout: int = 600) -> str:
         sys.path.insert(0, {str(refdrive.reference_root())!r}); sys.path.insert(0, {str(ROOT)!r})
         import random, torch
         import mini_sglang_amd.minisgl_plugin as plugin
-        plugin.install(gemm_tune="off")
+        plugin.install(gemm_tune="off", native_radix=False, vectorized_glue=False)  # the tests below compare the reference's own pieces with ours
         import minisgl.core as core
         from minisgl.core import Context
         import minisgl.kvcache.radix_cache as rc

@@ -124,7 +124,7 @@ def test_vectorized_scheduler_glue_equals_the_reference_functions():
                 return wrapped
             torch.empty, torch.tensor = _no_pin(torch.empty), _no_pin(torch.tensor)
         import mini_sglang_amd.minisgl_plugin as plugin
-        plugin.install(gemm_tune="off")
+        plugin.install(gemm_tune="off", vectorized_glue=False)  # `ref` below must be the reference's own functions
         import minisgl.scheduler.scheduler as sched
         from minisgl.core import Batch, Req, SamplingParams
         from mini_sglang_amd import sched_glue

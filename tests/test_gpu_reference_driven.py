@@ -403,6 +403,7 @@ def test_reference_driven_qwen3_14b_decode_step_is_the_benchmarked_path(dev):
               max_extend_tokens=16384, cache_type="radix", memory_ratio=0.9)
     rec = refdrive.run_worker(
         dict(model="qwen3-14b", weights="dummy", llm_kwargs=kw, record="timing", gemm_tune="full",
+             vectorized_glue=True, native_radix=True,   # install()'s defaults: the drop-in path as a user gets it
              rounds=[dict(prompts=[[1, 2, 3, 4]], sampling=[dict(temperature=0.1, max_tokens=4, ignore_eos=True)]),
                      dict(prompts=prompts, sampling=[sp] * B)]), timeout=1500)
     fw = [f for f in rec["forwards"] if f["round"] == 1]
@@ -416,6 +417,7 @@ def test_reference_driven_qwen3_14b_decode_step_is_the_benchmarked_path(dev):
                   wall_s=rec["walls"][1], e2e_tokens_per_s=B * steps / rec["walls"][1], init_s=rec["init_s"],
                   gemm=[dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], us=round(r["best_us"], 1),
                              kernel=r["kernel"][:80]) for r in rec["gemm_report"]],
+                  refined_in_graph=[dict(name=r["name"], chosen=r["chosen"], changed=r["changed"]) for r in rec.get("refine_report", [])],
                   driver="reference LLM/Scheduler/GraphRunner via minisgl_plugin.install()", device=rec["device"])
     print(f"\n[refdrive 14B] decode {med:.2f} ms/step ({B * 1e3 / med:.0f} tok/s) over {len(ms)} steps "
           f"[{ms[0]:.2f}..{ms[-1]:.2f}], prefill {len(pre)} chunks")

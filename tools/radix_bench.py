@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 import mini_sglang_amd.minisgl_plugin as plugin  # noqa: E402
 
-plugin.install(gemm_tune="off")
+plugin.install(gemm_tune="off", native_radix=False, vectorized_glue=False)
 import minisgl.core as core  # noqa: E402
 from minisgl.core import Context  # noqa: E402
 from minisgl.kvcache import create_prefix_cache  # noqa: E402
