@@ -863,14 +863,22 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
 // ------------------------------------------------------------------------------
 // merge split-KV partials: one wave per (request, q head), 2 output dims per lane
 // ------------------------------------------------------------------------------
+// launched_slots: slots the attention launch in front of this one had waves for.  The plan is made (and its slot count
+// fixed) by an earlier launch; if the kernel selection changed in between (msgl_attn_decode_select between a plan /
+// a graph capture and a later launch) the grid can be short of the plan's slots, pieces are then never computed and
+// this kernel would add uninitialised partial sums: it NaN-poisons every output row instead (loud, not plausible).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int batch) {
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int batch, int launched_slots) {
   constexpr int D = 128;
   const int lane = threadIdx.x & 63;
   const int w = sgpr((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
   if (w >= batch * p.hq) return;
   const int b = w / p.hq;
   const int hq = w - b * p.hq;
+  if (p.plan[3] > launched_slots) {
+    reinterpret_cast<uint32_t*>(p.out + (int64_t)b * p.out_stride + (int64_t)hq * D)[lane] = 0xffffffffu;
+    return;
+  }
   const int* item_start = p.plan + plan_off_item_start();
   const int* n_chunks = p.plan + plan_off_n_chunks(p.max_bs);
   const int n = sgpr(n_chunks[b]);
@@ -951,7 +959,7 @@ static int launch_decode_run(const DecodeParams& p, int batch, int capacity, hip
   const int64_t blocks = (waves + kWPB - 1) / kWPB;
   attn_decode_kernel<T, G, kRun><<<dim3((unsigned)blocks), dim3(64 * kWPB), 0, s>>>(p);
   const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
-  attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
+  attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch, (int)(blocks * kWPB / p.hv));
   return MSGL_OK;
 }
 
@@ -1010,7 +1018,7 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
 #undef MSGL_MFMA_LAUNCH
   if (!combine) {
     const int64_t mblocks = ((int64_t)batch * p.hq + 3) / 4;
-    attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch);
+    attn_decode_merge_kernel<T><<<dim3((unsigned)mblocks), dim3(256), 0, s>>>(p, batch, (int)(waves / p.hv));
   }
   return MSGL_OK;
 }

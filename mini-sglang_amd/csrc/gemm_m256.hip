@@ -8,12 +8,13 @@
 //     wave (mi, ni) owns x rows [128 mi, +128) x weight rows [32 ni, +32) => 4 accumulators of 32x32 per wave
 //     (v_mfma_f32_32x32x16: the weight fragment is the A operand and is reused across the 4 x blocks; half the LDS
 //     bytes per MFMA cycle of the 16x16x32 form the M <= 128 kernel (gemm_wstream.hip) uses);
-//   * both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging) into a ring of
-//     three 48-KB stages (x tile 256 x 128 B, w tile 128 x 128 B); one counted vmcnt + one raw s_barrier per step,
-//     two stages in flight while the third is computed;
-//   * LDS image: 128-B rows, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7) -- applied on the SOURCE address of
-//     the DMA (the LDS side of a DMA is lane-linear), conflict-free for the ds_read_b128 lane groups of a
-//     32-row fragment read (MI355X_MICROARCH.md, LDS table);
+//   * both operands are staged global -> VGPR -> LDS (16-B loads, ds_write_b128) into TWO 48-KB stages (x tile
+//     256 x 128 B, w tile 128 x 128 B): tile t + 2 is requested into registers while tile t is computed and tile
+//     t + 1 (requested one step earlier) is written to the other stage; one __syncthreads per step.  (The LDS-DMA
+//     three-stage ring this kernel started with is what csrc/gemm_g3.hip does with dedicated loader waves; issued by
+//     the MFMA waves themselves it lost to register staging, profiles/r02b_m256_gemm_ablation.txt.)
+//   * LDS image: 128-B rows, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7), conflict-free for the ds_read_b128
+//     lane groups of a 32-row fragment read (MI355X_MICROARCH.md, LDS table);
 //   * work split for balance, not for tiles: the first `full` tiles are computed whole (bf16 out staged through
 //     LDS for full-line stores); the remaining tiles are cut into `tail_split` k-slices spread over ALL
 //     workgroups, written as fp32 slabs and added in slice order by a small second kernel (deterministic).

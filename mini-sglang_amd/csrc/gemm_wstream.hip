@@ -233,9 +233,11 @@ static int launch_wstream(uint16_t* out, float* part, const uint16_t* x, const u
 #define MSGL_WS(MT_, NT_) \
   if (MT == MT_ && row_tiles == NT_) \
     return launch_wstream_t<T, MT_, NT_>(out, part, x, w, M, N, K, ldx, ldw, ldo, k_splits, s)
-  MSGL_WS(4, 1); MSGL_WS(4, 2); MSGL_WS(8, 1); MSGL_WS(8, 2); MSGL_WS(16, 1); MSGL_WS(16, 2);
+  // (16, 2) -- 256 rows x two weight tiles per wave -- needs 128 accumulator registers on top of the four-deep weight
+  // ring and spilled 91-96 VGPRs: not built; M > 128 takes one row tile (or the full-batch kernels of gemm_g3 / m256)
+  MSGL_WS(4, 1); MSGL_WS(4, 2); MSGL_WS(8, 1); MSGL_WS(8, 2); MSGL_WS(16, 1);
 #undef MSGL_WS
-  set_error("wstream_gemm_nt: row_tiles %d unsupported (1, 2)", row_tiles);
+  set_error("wstream_gemm_nt: row_tiles %d unsupported at M = %d (1, or 2 up to M = 128)", row_tiles, M);
   return MSGL_EINVAL;
 }
 

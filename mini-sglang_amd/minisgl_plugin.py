@@ -326,6 +326,23 @@ def _deferred_reduce_weights(model: Any) -> set:
                         walk(s)
 
     walk(model)
+
+    # the LAST layer's down_proj feeds the model's final norm (P/models/qwen3.py:62-63: `self.norm.forward(x, residual)`):
+    # deferred only if that norm is the fused-add kind whose shim adds the slabs; anything else reads `x` as a tensor
+    def final_norms(op: Any):
+        layers, norm = getattr(op, "layers", None), getattr(op, "norm", None)
+        if layers is not None and norm is not None and getattr(layers, "op_list", None):
+            yield layers.op_list[-1], norm
+        if isinstance(op, BaseOP):
+            for sub in vars(op).values():
+                for s_ in (sub if isinstance(sub, (list, tuple)) else (sub,)):
+                    if isinstance(s_, BaseOP):
+                        yield from final_norms(s_)
+
+    for last, norm in final_norms(model):
+        down = getattr(getattr(last, "mlp", None), "down_proj", None)
+        if down is not None and type(norm) is not RMSNormFused:
+            ptrs.discard(down.weight.data_ptr())
     return ptrs
 
 

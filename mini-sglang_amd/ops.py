@@ -564,7 +564,7 @@ def wstream_candidates(M: int, N: int, K: int):
     GEMM workspace."""
     out = []
     for nt in (1, 2):
-        if N % (128 * nt):
+        if N % (128 * nt) or (nt == 2 and M > 128):  # two row tiles per wave at M > 128 spill: not built
             continue
         groups = N // (128 * nt)
         for ks in (1, 2, 3, 4, 6, 8, 12, 16):
