@@ -236,6 +236,9 @@ class HybridCommunicator:
         self.p2p, self.rccl = p2p, rccl
         self.rank = (p2p or rccl).rank
         self.world_size = (p2p or rccl).world_size
+        # a second, independent communicator for collectives issued on a side stream while this one is busy on the
+        # compute stream (minisgl_plugin's row-parallel overlap); None unless init_pynccl(side=True) made one
+        self.side: Optional["HybridCommunicator"] = None
         _LIVE_COMMUNICATORS.add(self)
 
     def all_reduce(self, input: torch.Tensor, op: Literal["sum"] = "sum") -> None:
@@ -255,6 +258,8 @@ class HybridCommunicator:
         """Raise if a peer-to-peer barrier timed out (see P2PCommunicator.poll_error); RCCL reports through its calls."""
         if self.p2p is not None:
             self.p2p.poll_error(sync)
+        if self.side is not None:
+            self.side.poll_error(sync)
 
     def destroy(self) -> None:
         try:
@@ -264,6 +269,9 @@ class HybridCommunicator:
                 if c is not None:
                     c.destroy()
             _LIVE_COMMUNICATORS.discard(self)
+            if self.side is not None:
+                side, self.side = self.side, None
+                side.destroy()
 
 
 PyNCCLCommunicator = HybridCommunicator
@@ -276,7 +284,7 @@ def create_unique_id() -> bytes:
 
 
 def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int = 0,
-                backend: Optional[str] = None) -> HybridCommunicator:
+                backend: Optional[str] = None, side: Optional[bool] = None) -> HybridCommunicator:
     """P/kernel/pynccl.py:47-78.  backend: "hybrid" (peer-to-peer buffers of max_size_bytes + RCCL for larger
     messages), "rccl" (library only), "p2p" (mapped buffers only: every message must fit; the only choice when two
     ranks share a device).  RCCL bootstrap as in the reference: rank 0 creates the unique id, broadcast over the CPU
@@ -316,7 +324,15 @@ def init_pynccl(*, tp_rank: int, tp_size: int, tp_cpu_group, max_size_bytes: int
                 import sys
 
                 print(f"[msgl] peer-to-peer collectives disabled, RCCL carries every message: {problem}", file=sys.stderr)
-    return HybridCommunicator(p2p, rccl)
+    comm = HybridCommunicator(p2p, rccl)
+    # side=True (or MSGL_COMM_OVERLAP=1 when the reference calls us): a second communicator of the same kind for the
+    # side stream -- the same sequence of CPU-group exchanges on every rank, so all ranks must ask for it alike
+    if side is None:
+        side = os.environ.get("MSGL_COMM_OVERLAP", "0") == "1"
+    if side and tp_size > 1:
+        comm.side = init_pynccl(tp_rank=tp_rank, tp_size=tp_size, tp_cpu_group=tp_cpu_group, max_size_bytes=max_size_bytes,
+                                backend=backend, side=False)
+    return comm
 
 
 __all__ = ["indexing", "fast_compare_key", "store_cache", "init_pynccl", "PyNCCLCommunicator", "RcclCommunicator",

@@ -155,6 +155,71 @@ def _install_fused_attention() -> None:
     _STATE["fused_attention"] = True
 
 
+# ------------------------------------------------------------------------------ row-parallel projections: side-stream overlap
+def _install_row_parallel_overlap() -> None:
+    """`LinearOProj.forward` / `LinearRowParallel.forward` (P/layers/linear.py:102-106, 123-127) are
+    `y = F.linear(x, w, b); y = self._comm.all_reduce(y)` on one stream.  north_star: "RCCL all-reduce over xGMI
+    overlapped on a side HIP stream".  With at least MSGL_COMM_SPLIT_TOKENS tokens (default 2048: prefill chunks; a decode
+    batch would stream the weights twice for nothing) and a second communicator at hand (init_pynccl(side=True) /
+    MSGL_COMM_OVERLAP=1 -- two collectives of ONE communicator must never be in flight at once), the projection runs per
+    token half: the first half's all-reduce goes to the side stream through the second communicator while the compute
+    stream runs the second half's GEMM; the second half's all-reduce follows on the compute stream, which then waits for
+    the side stream.  The same split rule and kernels as model.DenseDecoder.row_parallel (bit-identical to it and to the
+    serial issue of the same kernels).  Anything else (bias, tp = 1, small batches, capture) takes the reference's
+    forward unchanged."""
+    import torch
+
+    from minisgl.layers.linear import LinearOProj, LinearRowParallel
+
+    split_tokens = int(os.environ.get("MSGL_COMM_SPLIT_TOKENS", "2048"))
+
+    def side_comm():
+        import minisgl.distributed.impl as dimpl
+
+        comm = getattr(dimpl.DistributedCommunicator.plugins[-1], "comm", None)
+        return comm, getattr(comm, "side", None)
+
+    def wrap(cls):
+        if getattr(cls.forward, "_msgl_overlap", False):
+            return
+        reference_forward = cls.forward
+
+        def forward(self, x):
+            T = x.shape[0] if x.dim() == 2 else 0
+            if (self._tp_size == 1 or self.bias is not None or split_tokens <= 0 or T < split_tokens or not x.is_cuda
+                    or torch.cuda.is_current_stream_capturing()):
+                return reference_forward(self, x)
+            comm, side = side_comm()
+            if comm is None or side is None:
+                return reference_forward(self, x)
+            from . import ops
+
+            h = (T // 2 + 7) // 8 * 8
+            y = torch.empty((T, self.weight.shape[0]), dtype=x.dtype, device=x.device)
+            ops.linear(x[:h], self.weight, out=y[:h])
+            main = torch.cuda.current_stream()
+            stream = _STATE.get("side_stream")
+            if stream is None or stream.device != x.device:
+                stream = _STATE["side_stream"] = torch.cuda.Stream(device=x.device)
+            stream.wait_event(main.record_event())
+            with torch.cuda.stream(stream):
+                side.all_reduce(y[:h], "sum")
+                done = stream.record_event()
+            ops.linear(x[h:], self.weight, out=y[h:])
+            comm.all_reduce(y[h:], "sum")
+            main.wait_event(done)
+            _STATE["overlapped_projections"] = _STATE.get("overlapped_projections", 0) + 1
+            return y
+
+        forward._msgl_overlap = True  # type: ignore[attr-defined]
+        forward._msgl_reference = reference_forward  # type: ignore[attr-defined]
+        cls.forward = forward
+
+    wrap(LinearOProj)
+    wrap(LinearRowParallel)
+    _STATE["row_parallel_overlap"] = True
+
+
 # ------------------------------------------------------------------------------ fused gate_up projection + SiLU.mul
 def _install_fused_gated_mlp() -> None:
     """`GatedMLP.forward` (P/models/utils.py:45-51) = gate_up_proj (F.linear, P/layers/linear.py:32) -> act_fn
@@ -516,10 +581,13 @@ def gemm_report() -> List[dict]:
 
 
 def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention: bool = True, fused_mlp: bool = True,
+            comm_overlap: bool = True,
             gemm_tune: Optional[str] = None, deterministic_decode_order: Optional[bool] = None, native_radix: bool = True,
             vectorized_glue: bool = True) -> None:
     """gemm_tune: "off" | "heuristic" | "full" (default: $MSGL_GEMM_TUNE or "heuristic").
     fused_mlp: gate_up_proj + silu_and_mul of the dense GatedMLP as ops.linear_silu (weights interleaved once, in place).
+    comm_overlap: under TP, row-parallel projections of >= $MSGL_COMM_SPLIT_TOKENS (2048) tokens run as two token halves with the
+        first half's all-reduce on a side stream (second communicator); see _install_row_parallel_overlap.
     deterministic_decode_order: decode batches in uid order instead of set-iteration order (reproducible KV indices);
         None (default) = only under tensor parallelism, where the replicated schedulers of the ranks MUST build the same
         batch (the reference's order is the iteration order of a set of id-hashed objects, i.e. heap addresses).
@@ -565,6 +633,9 @@ def install(stub_zmq: bool = True, *, fast_linear: bool = True, fused_attention:
         _install_fused_attention()
     if fused_mlp and fast_linear:
         _install_fused_gated_mlp()
+    if fast_linear and comm_overlap:
+        os.environ.setdefault("MSGL_COMM_OVERLAP", "1")  # init_pynccl (called by the reference) then builds the side communicator
+        _install_row_parallel_overlap()
     if deterministic_decode_order is None or deterministic_decode_order:
         _install_deterministic_decode_order(only_under_tp=deterministic_decode_order is None)
     _install_native_radix(replace_radix=native_radix)

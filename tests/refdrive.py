@@ -153,7 +153,7 @@ def run_tp_workers(spec: Dict[str, Any], tp_size: int, timeout: float = 900.0) -
         procs = []
         for r in range(tp_size):
             env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MSGL_REFDRIVE_RANK=str(r),
-                       GLOO_SOCKET_IFNAME="lo")
+                       GLOO_SOCKET_IFNAME="lo", **{k: str(v) for k, v in spec.get("env", {}).items()})
             env.pop("MSGL_GEMM_TUNE", None)
             procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "refdrive_worker.py"), str(spec_path),
                                            str(out_path), str(ref)], env=env, stdout=subprocess.PIPE,

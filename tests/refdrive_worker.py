@@ -53,18 +53,22 @@ def replay_through_repo_engine(spec, forwards, ref_engine, tp_rank, tp_size, rec
     group = dist.group.WORLD
     max_bytes = kw.get("max_extend_tokens", 8192) * PRESETS[spec["model"]].hidden_size * 2
 
+    split = int(os.environ.get("MSGL_COMM_SPLIT_TOKENS", "2048"))  # the plugin's rule: the repo engine must split alike
+
     def build(size, rank, comm):
         cfg = EngineConfig(model=PRESETS[spec["model"]], dtype=torch.bfloat16, tp_rank=rank, tp_size=size,
                            max_running_req=kw["max_running_req"], page_size=kw["page_size"],
                            cuda_graph_bs=list(rec["graph_bs"]), max_seq_len_override=kw["max_seq_len_override"],
                            num_page_override=rec["num_pages"], fused_qkv_path=True, gemm_tune="off", comm=comm,
+                           comm_side=getattr(comm, "side", None), comm_split_tokens=split if size > 1 else 0,
                            tp_cpu_group=group if size > 1 else None)
         eng = Engine(cfg, dev)
         eng.model.load_hf_state(state)
         return eng
 
     out = {}
-    comm = init_pynccl(tp_rank=tp_rank, tp_size=tp_size, tp_cpu_group=group, max_size_bytes=max_bytes, backend="p2p")
+    comm = init_pynccl(tp_rank=tp_rank, tp_size=tp_size, tp_cpu_group=group, max_size_bytes=max_bytes, backend="p2p",
+                       side=True)
     eng = build(tp_size, tp_rank, comm)
     same, tp_logits = [], []
     for f in forwards:
@@ -274,6 +278,8 @@ def main() -> None:
         rec["comm_p2p_error"] = comm.p2p.error() if getattr(comm, "p2p", None) is not None else None
         rec["comm_has_rccl"] = getattr(comm, "rccl", None) is not None
         rec["interleaved_mlps"] = plugin._STATE.get("interleaved_mlps")
+        rec["overlapped_projections"] = plugin._STATE.get("overlapped_projections", 0)
+        rec["comm_has_side"] = getattr(comm, "side", None) is not None
     if spec.get("replay_repo_engine"):
         rec["repo_replay"] = replay_through_repo_engine(spec, forwards, engine, tp_rank, tp_size, rec)
     try:

