@@ -375,6 +375,15 @@ int msgl_p2p_open(msgl_p2p_t comm, const void* all_handles /* world_size x MSGL_
 int msgl_p2p_configure(msgl_p2p_t comm, size_t one_shot_max_bytes, int blocks);
 int msgl_p2p_all_reduce_sum(msgl_p2p_t comm, void* data, size_t count, int dtype, void* stream);
 int msgl_p2p_all_gather(msgl_p2p_t comm, void* dst, const void* src, size_t count, int dtype, void* stream);
+/* all-reduce + residual add + RMSNorm as one launch for decode-size row blocks: the reference's
+ * `y = self._comm.all_reduce(F.linear(...))` (P/layers/linear.py:102-106, 123-127) followed by RMSNormFused's
+ * fused_add_rmsnorm (P/layers/norm.py:33-38).  x [rows, dim] = this rank's partial projection in, normalised output
+ * out; residual in / out.  Bit-identical to msgl_p2p_all_reduce_sum + msgl_fused_add_rmsnorm on every rank.  Returns
+ * MSGL_EINVAL for shapes it does not cover (more than 512 rows per call, dim > 8192, message above the
+ * buffer): the caller then issues the two launches. */
+int msgl_p2p_all_reduce_add_rmsnorm(msgl_p2p_t comm, void* x, void* residual, const void* weight, float eps,
+                                    int64_t rows, int64_t dim, int64_t x_stride, int64_t res_stride, int dtype,
+                                    void* stream);
 /* A barrier that gives up (a peer did not arrive within the spin limit) sets a sticky error word (1 + phase) and the
  * kernel POISONS its output with NaN bit patterns instead of returning a partial sum; once the word is set every later
  * collective of the communicator poisons at once (no further spinning).  msgl_p2p_error reads the word (synchronises

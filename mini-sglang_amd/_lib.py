@@ -78,6 +78,7 @@ HIP_SIGNATURES = {
     "msgl_p2p_configure": (_i, [_p, _sz, _i]),
     "msgl_p2p_all_reduce_sum": (_i, [_p, _p, _sz, _i, _p]),
     "msgl_p2p_all_gather": (_i, [_p, _p, _p, _sz, _i, _p]),
+    "msgl_p2p_all_reduce_add_rmsnorm": (_i, [_p, _p, _p, _p, _f, _l, _l, _l, _l, _i, _p]),
     "msgl_p2p_error": (_i, [_p]),
     "msgl_p2p_error_async": (_i, [_p, _p, _p]),
     "msgl_p2p_set_spin_limit": (_i, [_p, C.c_uint32]),

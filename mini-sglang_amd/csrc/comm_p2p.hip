@@ -172,6 +172,119 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// all-reduce + residual add + RMSNorm in ONE kernel (decode-size row blocks): what the reference runs as
+// `y = all_reduce(F.linear(x, w))` (P/layers/linear.py:102-106, 123-127) followed by RMSNormFused's
+// fused_add_rmsnorm(y, residual, weight, eps) (P/layers/norm.py:33-38; P/models/qwen3.py:36-41).
+//
+// Two-shot exchange partitioned by ROWS: block b handles rows [b rpb, (b + 1) rpb) on EVERY rank (a block synchronises
+// only with the same block index on the peers); row i is owned by rank i / per.  Copy my partial rows in -> barrier ->
+// the owner sums its rows over the ranks in rank order and parks the sum, ROUNDED TO THE 16-BIT TYPE (= the
+// all-reduce's output), in its result area -> barrier -> every block gathers its rows from their owners -- all
+// requests in flight at once, one 16-byte piece of a row per thread -- and finishes them itself: + residual (fp32),
+// residual <- rounded sum, x <- rmsnorm(fp32 sum) * weight.  The finishing arithmetic and its reduction order are
+// those of rmsnorm_wide_row_kernel (csrc/norm_rope_act.hip: one piece per thread, wave sums added in wave order), so
+// the result is bit-identical to all-reduce-then-norm, on every rank.  blockDim = dim / 8 rounded up to whole waves
+// (<= 1024); up to kFusedRows rows per block, finished TOGETHER (one LDS exchange for all of them).  The block count
+// stays that of the other collectives (a few dozen): every block pays three flag barriers with system-scope fences,
+// and one block per row (256 of them) measured 70 us per call where this form costs ~10.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kFusedRows = 8;
+
+template <typename T>
+__global__ __launch_bounds__(1024) void p2p_all_reduce_add_rmsnorm_kernel(P2PPeers peers, int rank, int world, U4* x,
+                                                                          U4* residual, const U4* __restrict__ weight,
+                                                                          float eps, int rows, int ppr, int64_t xs,
+                                                                          int64_t rs, int64_t area_packs,
+                                                                          uint32_t spin_limit) {
+  U4* mine = reinterpret_cast<U4*>(peers.base[rank] + kP2PHeaderBytes);
+  bool bad = p2p_sticky_error(peers, rank);
+  const int per = (rows + world - 1) / world;               // rows per owner
+  const int rpb = (rows + (int)gridDim.x - 1) / (int)gridDim.x;  // rows per block (<= kFusedRows)
+  const int r0 = min((int)blockIdx.x * rpb, rows), r1 = min(r0 + rpb, rows);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const bool has = tid < ppr;
+  // 1. copy my partial rows in (x may be row-strided; the staging image is dense [rows][ppr])
+  for (int r = r0; r < r1; ++r)
+    for (int p = tid; p < ppr; p += nthr) mine[(int64_t)r * ppr + p] = x[(int64_t)r * xs + p];
+  bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
+  // 2. the rows of this block that I own: sum over the ranks in rank order, rounded -> my result area
+  {
+    U4* res = mine + area_packs;
+    for (int r = r0; r < r1; ++r) {
+      if (r / per != rank) continue;
+      for (int p = tid; p < ppr; p += nthr) {
+        const int64_t i = (int64_t)r * ppr + p;
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < world; ++k) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[k] + kP2PHeaderBytes)[i]);
+        res[i] = pack8f<T>(a);
+      }
+    }
+  }
+  bad = p2p_barrier(peers, rank, world, 1, true, spin_limit, bad);
+  // 3. gather this block's rows from their owners (all loads first), then finish them together
+  __shared__ float lds_ss[kFusedRows][16];
+  U4 sum[kFusedRows], resq[kFusedRows];
+  const int n = r1 - r0;
+#pragma unroll
+  for (int k = 0; k < kFusedRows; ++k) {
+    if (k < n && has) {
+      const int r = r0 + k;
+      const U4* src = reinterpret_cast<const U4*>(peers.base[r / per] + kP2PHeaderBytes) + area_packs;
+      sum[k] = src[(int64_t)r * ppr + tid];
+      resq[k] = residual[(int64_t)r * rs + tid];
+    }
+  }
+  U4 wq = U4{0, 0, 0, 0};
+  if (has) wq = weight[tid];
+  const int w = tid >> 6, nw = (nthr + 63) >> 6;
+  auto row_values = [&](int k, float (&v)[8]) {  // fp32 (all-reduced x, rounded) + residual of this thread's piece
+    float rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    acc8<T>(v, sum[k]);
+    acc8<T>(rr, resq[k]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+  };
+#pragma unroll
+  for (int k = 0; k < kFusedRows; ++k) {
+    if (k >= n) break;
+    float ss = 0.f;
+    if (has) {
+      float v[8];
+      row_values(k, v);
+      residual[(int64_t)(r0 + k) * rs + tid] = bad ? p2p_poison() : pack8f<T>(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+    }
+    ss = wave_sum(ss);  // common.h: the association rmsnorm_wide_row_kernel uses
+    if ((tid & 63) == 0) lds_ss[k][w] = ss;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kFusedRows; ++k) {
+    if (k >= n) break;
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += lds_ss[k][i];
+    const float inv = rsqrtf(tot / (float)(ppr * 8) + eps);
+    if (has) {
+      float v[8], wf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, y[8];
+      row_values(k, v);
+      acc8<T>(wf, wq);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(__fmul_rn(v[e], inv), wf[e]);
+      x[(int64_t)(r0 + k) * xs + tid] = bad ? p2p_poison() : pack8f<T>(y);
+    }
+  }
+  bad = p2p_barrier(peers, rank, world, 2, false, spin_limit, bad);  // nobody refills its areas while a peer still reads
+  if (bad && has)
+    for (int r = r0; r < r1; ++r) {
+      x[(int64_t)r * xs + tid] = p2p_poison();
+      residual[(int64_t)r * rs + tid] = p2p_poison();
+    }
+}
+
 // dst[r * packs + i] = src_of_rank_r[i]
 __global__ __launch_bounds__(kP2PThreads) void p2p_all_gather_kernel(P2PPeers peers, int rank, int world, U4* dst,
                                                                      const U4* src, int64_t packs,
@@ -310,6 +423,46 @@ extern "C" int msgl_p2p_all_reduce_sum(msgl_p2p_t c, void* data, size_t count, i
   else { if (two) MSGL_P2P(FP16, true); else MSGL_P2P(FP16, false); }
 #undef MSGL_P2P
   MSGL_CHECK_LAUNCH("p2p_all_reduce");
+  return MSGL_OK;
+}
+
+// x [rows, dim] (row stride x_stride elements) <- rmsnorm(sum over ranks of x + residual) * weight, residual <- the rounded
+// sum, as ONE launch; every rank calls it with its own partial x and the same residual.  Returns MSGL_EINVAL (with a
+// message) for what the kernel does not cover -- the caller then runs msgl_p2p_all_reduce_sum + msgl_fused_add_rmsnorm.
+extern "C" int msgl_p2p_all_reduce_add_rmsnorm(msgl_p2p_t c, void* x, void* residual, const void* weight, float eps,
+                                               int64_t rows, int64_t dim, int64_t x_stride, int64_t res_stride, int dtype,
+                                               void* stream) {
+  MSGL_REQUIRE(c && x && residual && weight, "p2p_all_reduce_add_rmsnorm: null pointer");
+  MSGL_REQUIRE(dtype == MSGL_BF16 || dtype == MSGL_FP16, "p2p_all_reduce_add_rmsnorm: dtype code %d unsupported", dtype);
+  MSGL_REQUIRE(rows >= 1 && dim >= 8 && dim % 8 == 0 && dim <= 8192, "p2p_all_reduce_add_rmsnorm: %lld rows x %lld",
+               (long long)rows, (long long)dim);
+  MSGL_REQUIRE(x_stride % 8 == 0 && res_stride % 8 == 0 && x_stride >= dim && res_stride >= dim && aligned16(x) &&
+                   aligned16(residual) && aligned16(weight),
+               "p2p_all_reduce_add_rmsnorm: strides / alignment");
+  const size_t bytes = (size_t)rows * (size_t)dim * 2;
+  MSGL_REQUIRE(bytes <= c->max_bytes, "p2p_all_reduce_add_rmsnorm: %zu bytes exceed the buffer (%zu)", bytes, c->max_bytes);
+  if (int rc = p2p_ready(c, "p2p_all_reduce_add_rmsnorm")) return rc;
+  // the communicator's block count (that of the other collectives) while kFusedRows rows per block suffice, more up to
+  // the flag rows of the header
+  MSGL_REQUIRE(rows <= (int64_t)kP2PMaxBlocks * kFusedRows, "p2p_all_reduce_add_rmsnorm: %lld rows (at most %d)",
+               (long long)rows, kP2PMaxBlocks * kFusedRows);
+  int blocks = c->blocks;
+  while ((rows + blocks - 1) / blocks > kFusedRows) ++blocks;
+  const int rpb = (int)((rows + blocks - 1) / blocks);
+  blocks = (int)((rows + rpb - 1) / rpb);
+  const int ppr = (int)(dim / 8);
+  const unsigned threads = (unsigned)((ppr + 63) / 64 * 64);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t area = (int64_t)(c->max_bytes / 16);
+  if (dtype == MSGL_BF16)
+    p2p_all_reduce_add_rmsnorm_kernel<BF16><<<dim3((unsigned)blocks), dim3(threads), 0, s>>>(
+        c->peers, c->rank, c->world, (U4*)x, (U4*)residual, (const U4*)weight, eps, (int)rows, ppr, x_stride / 8,
+        res_stride / 8, area, c->spin_limit);
+  else
+    p2p_all_reduce_add_rmsnorm_kernel<FP16><<<dim3((unsigned)blocks), dim3(threads), 0, s>>>(
+        c->peers, c->rank, c->world, (U4*)x, (U4*)residual, (const U4*)weight, eps, (int)rows, ppr, x_stride / 8,
+        res_stride / 8, area, c->spin_limit);
+  MSGL_CHECK_LAUNCH("p2p_all_reduce_add_rmsnorm");
   return MSGL_OK;
 }
 

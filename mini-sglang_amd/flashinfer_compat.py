@@ -25,9 +25,14 @@ def rmsnorm(input: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
 def fused_add_rmsnorm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
                       enable_pdl: Optional[bool] = None) -> None:
     slabs = getattr(input, "_msgl_slabs", None)
+    comm = getattr(input, "_msgl_allreduce", None)
     if slabs is not None:  # output of a split-K projection whose reduce was left to this kernel (ops.linear_slabs)
         del input._msgl_slabs
         ops.fused_add_rmsnorm_slabs(input, residual, weight, eps, slabs)
+    elif comm is not None:  # output of a row-parallel projection whose all-reduce was left to this norm (TP decode)
+        del input._msgl_allreduce
+        ops._PENDING_ALLREDUCE[input.device.index or 0] = None
+        comm.all_reduce_add_rmsnorm(input, residual, weight, eps)
     else:
         ops.fused_add_rmsnorm(input, residual, weight, eps)
 

@@ -172,6 +172,22 @@ class P2PCommunicator:
                                                   ops._dt(input), torch.cuda.current_stream().cuda_stream),
                    "p2p_all_gather")
 
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> bool:
+        """x <- rmsnorm(all_reduce(x) + residual) * weight, residual <- the rounded sum, in ONE launch (the row-parallel
+        projection's all-reduce fused with the RMSNormFused that follows it, P/layers/linear.py:102-106 + P/layers/norm.py:
+        33-38).  Returns False -- nothing launched -- for shapes the kernel does not cover (the caller then issues
+        all_reduce + fused_add_rmsnorm); bit-identical to that pair."""
+        rows, dim = x.shape
+        if (x.dim() != 2 or x.stride(1) != 1 or residual.stride(1) != 1 or residual.shape != x.shape or dim % 8 or dim > 8192
+                or rows < 1 or rows > 512 or rows * dim * x.element_size() > self.max_bytes or x.data_ptr() % 16
+                or residual.data_ptr() % 16):
+            return False
+        _lib.check(self._lib.msgl_p2p_all_reduce_add_rmsnorm(self._handle, x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                                             float(eps), rows, dim, x.stride(0), residual.stride(0), ops._dt(x),
+                                                             torch.cuda.current_stream().cuda_stream),
+                   "p2p_all_reduce_add_rmsnorm")
+        return True
+
     def error(self) -> int:
         """0, or 1 + the barrier phase that timed out (sticky; synchronises the device)."""
         return int(self._lib.msgl_p2p_error(self._handle))
@@ -250,6 +266,14 @@ class HybridCommunicator:
         if self.p2p is not None and (self.rccl is None or self.p2p.fits(input)):
             return self.p2p.all_gather(output, input)
         return self.rccl.all_gather(output, input)
+
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+        """all_reduce(x) followed by fused_add_rmsnorm(x, residual, weight, eps): one peer-to-peer launch where that
+        kernel applies (decode-size row blocks), else the two operations."""
+        if self.p2p is not None and self.p2p.all_reduce_add_rmsnorm(x, residual, weight, eps):
+            return
+        self.all_reduce(x, "sum")
+        ops.fused_add_rmsnorm(x, residual, weight, eps)
 
     def get_buffer(self) -> int:
         return (self.p2p or self.rccl).get_buffer()

@@ -186,6 +186,18 @@ def _install_row_parallel_overlap() -> None:
 
         def forward(self, x):
             T = x.shape[0] if x.dim() == 2 else 0
+            if (self._tp_size > 1 and self.bias is None and 0 < T < max(split_tokens, 1) and x.is_cuda
+                    and self.weight.data_ptr() in _STATE.get("deferred_allreduce_weights", ())):
+                # decode-size batch of a dense decoder layer: the tensor returned here goes, untouched, into the next
+                # RMSNormFused (fused_add_rmsnorm shim), which runs all-reduce + residual add + norm as ONE launch
+                comm, _side = side_comm()
+                if comm is not None and hasattr(comm, "all_reduce_add_rmsnorm") and x.dtype == self.weight.dtype:
+                    from . import ops
+
+                    y = ops.linear(x, self.weight)
+                    y._msgl_allreduce = comm
+                    ops._PENDING_ALLREDUCE[x.device.index or 0] = y
+                    return y
             if (self._tp_size == 1 or self.bias is not None or split_tokens <= 0 or T < split_tokens or not x.is_cuda
                     or torch.cuda.is_current_stream_capturing()):
                 return reference_forward(self, x)
@@ -346,7 +358,7 @@ def _projection_groups(model: Any, require_device: bool = True) -> List[tuple]:
     return groups
 
 
-def _deferred_reduce_weights(model: Any) -> set:
+def _deferred_reduce_weights(model: Any, tp_gt1: bool = False) -> set:
     """data_ptr of every projection weight whose output goes, untouched, into a kernel of ours that can add the
     projection's k-slice sums itself: o_proj and down_proj of the dense decoder layers into the next RMSNormFused's
     fused residual add (P/models/qwen3.py:37-41, llama.py:39-43, qwen2.py; the last layer's down_proj feeds the final
@@ -375,8 +387,11 @@ def _deferred_reduce_weights(model: Any) -> set:
                 and type(getattr(op, "input_layernorm", None)) is RMSNormFused):
             o, down = getattr(attn, "o_proj", None), getattr(mlp, "down_proj", None)
             if (type(o) is LinearOProj and type(down) is LinearRowParallel and o.bias is None and down.bias is None
-                    and o._tp_size == 1 and down._tp_size == 1 and o.weight.is_cuda):
+                    and (o._tp_size > 1 and down._tp_size > 1 if tp_gt1 else o._tp_size == 1 and down._tp_size == 1)
+                    and o.weight.is_cuda):
                 ptrs.update((o.weight.data_ptr(), down.weight.data_ptr()))
+            if tp_gt1:  # only the row-parallel pair: qkv_proj has no all-reduce
+                return
             # qkv_proj -> AttentionLayer.forward (P/models/utils.py:118-123), column-parallel: any tp size; only when
             # that forward is the fused one installed above and the backend is ours
             qkv = getattr(attn, "qkv_proj", None)
@@ -473,6 +488,8 @@ def _install_tune_before_capture() -> None:
                 torch.cuda.synchronize(self.device)
         if _STATE["fast_linear"] and os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1":
             _STATE["deferred_reduce_weights"] = _deferred_reduce_weights(model)
+        if _STATE.get("row_parallel_overlap") and os.environ.get("MSGL_FUSED_ALLREDUCE_NORM") == "1":  # opt-in, see model.py
+            _STATE["deferred_allreduce_weights"] = _deferred_reduce_weights(model, tp_gt1=True)
         out = reference_capture(self, max_seq_len, vocab_size, model)
         world = 1
         try:

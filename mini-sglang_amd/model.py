@@ -29,6 +29,11 @@ from .kvcache import div_even
 # MSGL_DISABLE_SLAB_NORM=1: keep the split-K reduce of o_proj / down_proj as its own launch (A/B switch)
 _SLAB_NORM = os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1"
 _FUSE_SILU = os.environ.get("MSGL_DISABLE_FUSED_SILU") != "1"
+# all-reduce + residual add + RMSNorm as one peer-to-peer launch (csrc/comm_p2p.hip): OPT-IN.  The only measurement
+# available without a multi-GPU box -- one rank's shard with looped-back collectives, bench.py --rank-shard 4 -- has it
+# SLOWER than the two launches (10.24 vs 9.07 ms per step): the kernel keeps the few dozen blocks its flag barriers want,
+# and those cannot move the 10 MB of local x / residual traffic of a 256-row batch as fast as the 256-block norm kernel.
+_FUSE_AR_NORM = os.environ.get("MSGL_FUSED_ALLREDUCE_NORM") == "1"
 
 
 @dataclass(frozen=True)
@@ -109,6 +114,16 @@ class Communicator:
     def all_reduce_side(self, x: torch.Tensor) -> torch.Tensor:
         if self.tp_size > 1:
             (self.side or self.impl).all_reduce(x, "sum")
+        return x
+
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+        """all_reduce(x), then fused_add_rmsnorm(x, residual, weight, eps): ONE launch where the communicator has the
+        fused peer-to-peer kernel for the shape (decode batches), otherwise the two operations."""
+        if self.tp_size > 1 and hasattr(self.impl, "all_reduce_add_rmsnorm") and _FUSE_AR_NORM:
+            self.impl.all_reduce_add_rmsnorm(x, residual, weight, eps)
+            return x
+        self.all_reduce(x)
+        fi.fused_add_rmsnorm(x, residual, weight, eps)
         return x
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
@@ -287,6 +302,17 @@ class DenseDecoder:
             self.comm.all_reduce(y[h:])
         return y
 
+    def row_parallel_norm(self, x: torch.Tensor, w: torch.Tensor, residual: torch.Tensor, norm_w: torch.Tensor) -> torch.Tensor:
+        """fused_add_rmsnorm(all_reduce(x @ w^T), residual, norm_w) (P/models/qwen3.py:36-41): at tp = 1 the projection's
+        split-K reduce joins the norm (slab hand-off); at tp > 1 a decode-size batch takes the fused all-reduce + add +
+        norm launch of the peer-to-peer communicator, larger ones the (overlapped) all-reduce and then the norm."""
+        eps = self.cfg.rms_norm_eps
+        if self.tp_size > 1 and not (self.comm_split_tokens and x.shape[0] >= self.comm_split_tokens):
+            return self.comm.all_reduce_add_rmsnorm(ops.linear(x, w), residual, norm_w, eps)
+        y = self.row_parallel(x, w)
+        fi.fused_add_rmsnorm(y, residual, norm_w, eps)
+        return y
+
     # ------------------------------------------------------------------ forward
     def forward(self, ctx: Any, batch: Any, logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """P/models/qwen3.py:77-81 -> logits [B, vocab] (model dtype); written into `logits_out` (rows x vocab, model
@@ -297,11 +323,12 @@ class DenseDecoder:
                                  vocab_range=self.vocab_range if self.tp_size > 1 else None)
         x = self.comm.all_reduce(x)
         residual: Optional[torch.Tensor] = None
+        normed_ahead = False  # the previous layer's down_proj already ran this layer's input norm (row_parallel_norm)
         for li, lw in enumerate(self.layers):
             if residual is None:  # P/layers/norm.py:35-36
                 residual = x
                 x = fi.rmsnorm(x, lw.input_norm, cfg.rms_norm_eps)
-            else:
+            elif not normed_ahead:
                 fi.fused_add_rmsnorm(x, residual, lw.input_norm, cfg.rms_norm_eps)
             # a k-sliced full-batch plan leaves the qkv projection's reduce to the fused norm / RoPE / store pass
             qkv, slabs = ops.linear_slabs(x, lw.qkv) if self.fused and _SLAB_NORM else (ops.linear(x, lw.qkv), None)
@@ -324,14 +351,15 @@ class DenseDecoder:
                 fi.apply_rope_with_cos_sin_cache_inplace(positions=batch.positions, query=q, key=k, head_size=D,
                                                          cos_sin_cache=self.cos_sin)
                 o = backend.forward(q.view(-1, self.hq, D), k, v, li, batch)
-            x = self.row_parallel(o.view(-1, self.q_dim), lw.o)
-            fi.fused_add_rmsnorm(x, residual, lw.post_norm, cfg.rms_norm_eps)
+            x = self.row_parallel_norm(o.view(-1, self.q_dim), lw.o, residual, lw.post_norm)
             if self.gate_up_ilv:  # projection + SiLU.mul: one launch where planned (P/models/utils.py:45-51)
                 y = ops.linear_silu(x, lw.gate_up)
             else:
                 y = fi.silu_and_mul(ops.linear(x, lw.gate_up))
-            x = self.row_parallel(y, lw.down)
-        fi.fused_add_rmsnorm(x, residual, self.final_norm, cfg.rms_norm_eps)
+            # down_proj feeds the NEXT layer's input norm (or the final norm): its all-reduce / slab reduce joins that norm
+            nxt = self.layers[li + 1].input_norm if li + 1 < len(self.layers) else self.final_norm
+            x = self.row_parallel_norm(y, lw.down, residual, nxt)
+            normed_ahead = True
         # LM head (P/layers/embedding.py:88-110)
         bs = batch.size
         if batch.is_prefill:

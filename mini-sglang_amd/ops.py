@@ -157,7 +157,16 @@ class Slabs:
 _PENDING_SLABS: dict = {}
 
 
+# a row-parallel projection's output whose all-reduce was left to the fused all-reduce + add + RMSNorm launch of the norm
+# that follows (minisgl_plugin / flashinfer_compat): any other GEMM in between means it reached a different consumer
+_PENDING_ALLREDUCE: dict = {}
+
+
 def _no_pending_slabs(device: torch.device) -> None:
+    if _PENDING_ALLREDUCE and _PENDING_ALLREDUCE.get(device.index or 0) is not None:
+        _PENDING_ALLREDUCE[device.index or 0] = None
+        raise RuntimeError("a row-parallel projection's all-reduce was deferred to the fused all-reduce + RMSNorm launch, "
+                           "but its output reached a different consumer (no fused_add_rmsnorm followed it)")
     if _PENDING_SLABS and _PENDING_SLABS.get(device.index or 0) is not None:
         _PENDING_SLABS[device.index or 0] = None  # report once: a failed forward must not poison every later GEMM
         raise RuntimeError("a split-K projection's partial sums are still waiting for fused_add_rmsnorm_slabs: "
@@ -938,6 +947,7 @@ def reset_gemm_plans() -> None:
     _FUSED_SILU_PLAN.clear()
     _CANDIDATES.clear()
     _PENDING_SLABS.clear()
+    _PENDING_ALLREDUCE.clear()
     _lib.check_gemm(_lib.gemm_lib().msgl_gemm_reset_plans(), "gemm_reset_plans")
 
 

@@ -257,9 +257,10 @@ def test_reference_driven_tp2_through_the_plugin_two_ranks_on_one_gpu(dev, model
     kw = dict(page_size=4, max_running_req=8, cuda_graph_bs=[1, 2, 4, 8], max_seq_len_override=512, num_page_override=512,
               max_extend_tokens=96, cache_type="radix")
     # MSGL_COMM_SPLIT_TOKENS=32: the row-parallel side-stream overlap (2048 tokens by default) kicks in for this
-    # scenario's prefill chunks; the repo engine's replay splits by the same rule
+    # scenario's prefill chunks; the repo engine's replay splits by the same rule.  MSGL_FUSED_ALLREDUCE_NORM=1: smaller
+    # batches (decode) defer the all-reduce of o_proj / down_proj to the RMSNormFused that follows: ONE peer-to-peer launch
     spec = dict(model="tiny", model_dir=mdir, llm_kwargs=kw, deterministic_decode_order=True, full_logits_forwards=0,
-                replay_repo_engine=True, env=dict(MSGL_COMM_SPLIT_TOKENS=32),
+                replay_repo_engine=True, env=dict(MSGL_COMM_SPLIT_TOKENS=32, MSGL_FUSED_ALLREDUCE_NORM=1),
                 rounds=[dict(prompts=prompts, sampling=[greedy(6)] * len(prompts))])
     r0, r1 = refdrive.run_tp_workers(spec, 2)
     for r in (r0, r1):

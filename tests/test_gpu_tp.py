@@ -60,6 +60,7 @@ def test_p2p_collectives_known_answers(dev, world):
     res = launch("collectives", world)
     for r in res:
         assert r["error"] == 0, "a flag barrier timed out"
+        assert r["fused_allreduce_norm_shapes"] >= 4, "the fused all-reduce + add + RMSNorm kernel was not exercised"
     for name in ("one_shot", "two_shot", "ragged_two_shot"):
         for r in res[1:]:
             assert torch.equal(r[f"sum_{name}"], res[0][f"sum_{name}"]), f"ranks disagree on the {name} sum bits"

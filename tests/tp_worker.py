@@ -67,6 +67,29 @@ def collectives(rank: int, world: int, dev: torch.device) -> dict:
         comm.all_reduce(xh)
         torch.cuda.synchronize()
         assert bool((xh == 0.5 * world + world * (world - 1) / 2).all()), name
+    # fused all-reduce + residual add + RMSNorm == all-reduce, then fused_add_rmsnorm: same bits (x, residual), every rank
+    from mini_sglang_amd import ops
+
+    fused_checked = 0
+    for rows, dim, dt in ((256, 5120, torch.bfloat16), (130, 5120, torch.bfloat16), (8, 1024, torch.float16), (1, 8192, torch.bfloat16),
+                          (64, 128, torch.bfloat16)):
+        g = torch.Generator(device=dev).manual_seed(99 + rows)
+        parts = [torch.randn((rows, dim), generator=g, device=dev).to(dt) for _ in range(world)]
+        res0 = torch.randn((rows, dim), generator=g, device=dev).to(dt)
+        wn = (1 + 0.1 * torch.randn(dim, generator=g, device=dev)).to(dt)
+        xa, ra = parts[rank].clone(), res0.clone()
+        comm.all_reduce(xa)
+        ops.fused_add_rmsnorm(xa, ra, wn, 1e-6)
+        big = torch.zeros((rows, dim + 64), dtype=dt, device=dev)   # row-strided x as well
+        xb, rb = big[:, :dim], res0.clone()
+        xb.copy_(parts[rank])
+        used = comm.all_reduce_add_rmsnorm(xb, rb, wn, 1e-6)
+        torch.cuda.synchronize()
+        if used:
+            assert torch.equal(xa, xb) and torch.equal(ra, rb), (rows, dim, dt)
+            assert big[:, dim:].abs().max().item() == 0
+            fused_checked += 1
+    res["fused_allreduce_norm_shapes"] = fused_checked
     # all-gather of rank-valued chunks
     src = torch.full((64, 1184), float(rank), dtype=torch.bfloat16, device=dev)
     dst = torch.empty((64 * world, 1184), dtype=torch.bfloat16, device=dev)

@@ -53,6 +53,14 @@ class LoopbackCommunicator:
         self.p2p.all_gather(output[:rows], input)
         output.view(self.tp_size, rows, *input.shape[1:])[1:] = input  # the peers' shards arriving
 
+    def all_reduce_add_rmsnorm(self, x, residual, weight, eps) -> None:
+        from mini_sglang_amd import ops
+
+        self.calls += 1
+        if not self.p2p.all_reduce_add_rmsnorm(x, residual, weight, eps):
+            self.p2p.all_reduce(x, "sum")
+            ops.fused_add_rmsnorm(x, residual, weight, eps)
+
     def poll_error(self, sync: bool = False) -> None:
         self.p2p.poll_error(sync)
 
