@@ -2,7 +2,7 @@
 # End-of-round validation on the GPU box (run through gpurun from the repo root): GPU parity suite, the driver's bench
 # command, rocprofv3 kernel trace of the same command, PMC traffic passes of the dominant kernel.  Every step is
 # bounded by `timeout`; summaries land in gpurun_out/<tag>_* (copy what is to be judged into profiles/).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -42,6 +42,19 @@ grep algorithmic $R/gpurun_out/${TAG}_attn_kt.log
 ALGO=$(grep algorithmic_bytes_per_launch $R/gpurun_out/${TAG}_attn_kt.log | awk '{print $2}')
 python $R/tools/pmc_json.py $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt \
   $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt $ALGO $R/gpurun_out/${TAG}_pmc_attn_decode.json "validate_round.sh $TAG" | cut -c1-400
+# PMC passes over the M = 256 projection path (per GEMM kernel, slab consumers), rank-shard TP bounds
+cd $R
+bash tools/pmc_gemm.sh ${TAG} > gpurun_out/${TAG}_pmc_gemm.log 2>&1; grep -c "," gpurun_out/${TAG}_pmc_gemm_FETCH_SIZE.txt
+MS=$(python - <<PY
+import json
+try:
+    print(round(json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])["ms_per_step"], 3))
+except Exception:
+    print(17.8)
+PY
+)
+for cfg in "qwen3-14b 2" "qwen3-14b 4" "qwen3-14b 8" "qwen3-32b 4"; do set -- $cfg; timeout 200 python bench.py --model $1 --rank-shard $2 --tp1-ms $MS --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_rank_shard_$1_tp$2.json; cut -c1-200 gpurun_out/${TAG}_rank_shard_$1_tp$2.json; done
+bash tools/trace_small_batch.sh ${TAG} 1 > gpurun_out/${TAG}_b1_trace.log 2>&1; head -3 gpurun_out/${TAG}_b1_kernel_breakdown.txt
 # same-box A/B of the decode attention kernels, per-wave clock stamps of the default one, MFMA counters of prefill attention
 cd $R
 timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,0.6b,14b_b32 --impls 1,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
