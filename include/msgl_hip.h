@@ -221,7 +221,7 @@ int msgl_attn_decode_trace(void* stamps);
  * q: [T, Hq, D] (tokens of all requests concatenated, cu_seqlens_q [B+1]);
  * request b attends keys 0..seq_lens[b]-1 through the page table; query j of
  * q_len sees keys t <= seq_lens[b] - q_len + j (bottom-right causal mask).
- * tile_cu [B+1]: exclusive prefix of ceil(q_len_b / MSGL_PREFILL_QTILE).
+ * tile_cu [B+1]: exclusive prefix of ceil(q_len_b / msgl_attn_prefill_q_tile(impl)).
  * ---------------------------------------------------------------------- */
 #define MSGL_PREFILL_QTILE 128
 int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
@@ -236,7 +236,15 @@ int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void*
  * tiles (results do not depend on it).  impl: 0 = default, 1 = first-generation kernel (V transposed
  * while staging), 2 = ds_read_b64_tr_b16 kernel (double-buffered LDS, XCD-contiguous kv heads; softmax scale folded
  * into the exponent's fma), 3 = the same kernel with the scale applied before the row max (gen-1's arithmetic: the
- * bit-exact cross-check seam between the two generations). */
+ * bit-exact cross-check seam between the two generations), 4 = impl 2's math with K/V staged by DMA
+ * (global_load_lds_dwordx4), 5 = the counter-phase kernel: 8 waves per 256-ROW q tile, two wave groups alternating
+ * matrix and softmax segments (same math per row: impl 2, 4 and 5 give bit-identical results).  Other values are
+ * timing-only ablations of these kernels (tools/prefill_ablate.py). */
+/* Rows per q tile the kernel behind `impl` expects: tile_cu, total_tiles and tile_order of msgl_attn_prefill are in
+ * units of this many query rows (MSGL_PREFILL_QTILE for impl 1..4, 256 for impl 5). */
+int msgl_attn_prefill_q_tile(int impl);
+/* diagnosis: device buffer of 32 * 8 * 256 uint64 receiving s_memtime stamps of impl 5 + 128 (NULL: off); tools/prefill_trace.py */
+int msgl_attn_prefill_trace(void* stamps);
 
 /* ------------------------------------------------------------------------
  * Sampling.  Replaces torch.argmax at P/engine/sample.py:73-74 and

@@ -65,6 +65,8 @@ HIP_SIGNATURES = {
         _i,
         [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p, _i, _p],
     ),
+    "msgl_attn_prefill_q_tile": (_i, [_i]),
+    "msgl_attn_prefill_trace": (_i, [_p]),
     "msgl_argmax_rows": (_i, [_p, _p, _l, _l, _l, _i, _p]),
     "msgl_softmax_temperature": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_sample_top_k_top_p": (_i, [_p, _p, _p, _p, _l, _l, _l, _u64, _u64, _p]),

@@ -40,21 +40,25 @@ class HipAttnMetadata:
         return self.cu_seqlens_q[1: 1 + bs] - 1
 
 
-def prefill_tile_order(seqlens_q: np.ndarray, seqlens_k: np.ndarray, tiles: np.ndarray) -> np.ndarray:
-    """Launch order of the 128-row q tiles of a prefill batch: by decreasing number of keys the tile attends
-    (tile t of request b sees keys [0, min(k_b, k_b - q_b + min((t + 1) * 128, q_b)))), ties in natural order.
-    A scheduling hint only (longest-processing-time first shortens the launch tail); results do not depend on it."""
+def prefill_tile_order(seqlens_q: np.ndarray, seqlens_k: np.ndarray, tiles: np.ndarray,
+                       q_tile: Optional[int] = None) -> np.ndarray:
+    """Launch order of the q tiles (q_tile rows each; default: the default prefill kernel's) of a prefill batch: by
+    decreasing number of keys the tile attends (tile t of request b sees keys [0, min(k_b, k_b - q_b + min((t + 1) *
+    q_tile, q_b)))), ties in natural order.  A scheduling hint only (longest-processing-time first shortens the launch
+    tail); results do not depend on it."""
+    if q_tile is None:
+        q_tile = ops.prefill_q_tile()
     total = int(tiles.sum())
     req = np.repeat(np.arange(len(tiles)), tiles)
     first = np.cumsum(tiles) - tiles
     t_in = np.arange(total) - first[req]
     q, k = seqlens_q[req], seqlens_k[req]
-    kend = np.minimum(k, k - q + np.minimum((t_in + 1) * _lib.PREFILL_QTILE, q))
+    kend = np.minimum(k, k - q + np.minimum((t_in + 1) * q_tile, q))
     return np.argsort(-kend, kind="stable").astype(np.int32)
 
 
 def fill_metadata_host(h: np.ndarray, seqlens_q: np.ndarray, seqlens_k: np.ndarray, rows: np.ndarray,
-                       decode: bool) -> None:
+                       decode: bool, q_tile: int = _lib.PREFILL_QTILE) -> None:
     """Per-batch integers of `prepare_metadata` (fa.py:67-105) in one int32 buffer of 4 B + 2 (+ tiles) words:
     [seq_lens = device_len (cache_seqlens) | rows = table_idx | cu_seqlens_q [B+1] | tile_cu [B+1] | tile_order].
     cu_seqlens_q is the reference's in all three regimes (arange for decode, = cu_seqlens_k without a cache
@@ -65,10 +69,10 @@ def fill_metadata_host(h: np.ndarray, seqlens_q: np.ndarray, seqlens_k: np.ndarr
     h[2 * bs] = 0
     h[2 * bs + 1: 3 * bs + 1] = np.cumsum(seqlens_q)
     if not decode:
-        tiles = (seqlens_q + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE
+        tiles = (seqlens_q + q_tile - 1) // q_tile
         h[3 * bs + 1] = 0
         h[3 * bs + 2: 4 * bs + 2] = np.cumsum(tiles)
-        h[4 * bs + 2:] = prefill_tile_order(seqlens_q, seqlens_k, tiles)
+        h[4 * bs + 2:] = prefill_tile_order(seqlens_q, seqlens_k, tiles, q_tile)
 
 
 class HipAttnBackend:
@@ -86,6 +90,7 @@ class HipAttnBackend:
         self.head_dim = config.head_dim
         self.scale = config.head_dim ** -0.5
         self.tp_size = tp_size
+        self._q_tile = ops.prefill_q_tile()  # query rows per tile of the prefill kernel in use (unit of tile_cu / tile_order)
         self.qo_heads = config.num_qo_heads // tp_size
         self.kv_heads = max(config.num_kv_heads // tp_size, 1)
         self.max_bs = int(ctx.page_table.shape[0])
@@ -149,10 +154,11 @@ class HipAttnBackend:
         rows = np.fromiter((r.table_idx for r in reqs), dtype=np.int64, count=bs)
         max_q, max_k = int(seqlens_q.max()), int(seqlens_k.max())
         decode = max_q == 1
-        total_tiles = 0 if decode else int(((seqlens_q + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE).sum())
+        q_tile = self._q_tile
+        total_tiles = 0 if decode else int(((seqlens_q + q_tile - 1) // q_tile).sum())
         # one pinned buffer, one async H2D copy: [seq_lens | rows | cu_q | tile_cu | tile_order]
         host = torch.empty(4 * bs + 2 + total_tiles, dtype=torch.int32, pin_memory=True)
-        fill_metadata_host(host.numpy(), seqlens_q, seqlens_k, rows, decode)
+        fill_metadata_host(host.numpy(), seqlens_q, seqlens_k, rows, decode, q_tile)
         dev = host.to(self.device, non_blocking=True)
         md = HipAttnMetadata(
             cu_seqlens_q=dev[2 * bs: 3 * bs + 1], seq_lens=dev[:bs], req_rows=dev[bs: 2 * bs], batch=bs,

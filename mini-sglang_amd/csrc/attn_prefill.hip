@@ -61,7 +61,14 @@ struct PrefillParams {
   int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
   int batch, hq, group;
   float scale_log2;
+  unsigned long long* trace;  // diagnosis (msgl_attn_prefill_trace, impl 5 + 128): clock stamps per wave and period, else nullptr
 };
+
+// element offset of a pool slot: slot and the token stride are both < 2^32 (checked at launch), so ONE v_mad_u64_u32
+// does it; the int64 x int64 product the types ask for costs two quarter-rate 32-bit multiplies and a carry chain more
+__device__ __forceinline__ int64_t slot_offset(int slot, int64_t stride_tok) {
+  return (int64_t)((uint64_t)(uint32_t)slot * (uint64_t)(uint32_t)stride_tok);
+}
 
 // swizzles (see header comment): K image [64 keys][256 B], V^T image [128 d][128 B = 64 keys]
 __device__ __forceinline__ int k_off(int key, int byte_in_row) { return key * 256 + (byte_in_row ^ ((key & 15) << 4)); }
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Second-generation kernel (impl 2, the default): same math and fragment ownership as above, but
+// Second-generation kernel (impl 2; the default until the DMA-staged impl 4 below): same math and fragment ownership as above, but
 //   * V is staged ROW-major ([64 keys][256 B], like K: four ds_write_b128 per thread and tile instead of
 //     thirty-two 2-byte transposing stores) and the V^T MFMA fragments come out of LDS through the gfx950
 //     transposing read ds_read_b64_tr_b16: a 16-lane group reads one [4 keys][16 d] block (lane j passes the
@@ -281,13 +288,15 @@ __device__ __forceinline__ uint2 tr_read_b64(const char* lds_ptr) {
 
 constexpr int kTileBytes = kKTile * kD * 2;  // 16 KB: one K (or V) tile image
 
-template <typename T, bool kFold = true>
+// ABL (diagnosis only, wrong results): 1 = K/V tiles loaded once (no HBM/L2 stream, no LDS writes after the first tile),
+// 2 = no QK^T MFMAs, 4 = no softmax arithmetic, 8 = no PV MFMAs, 16 = no barrier after the first tile
+template <typename T, bool kFold = true, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillParams p, int total_tiles) {
   __shared__ __attribute__((aligned(16))) char lds[4 * kTileBytes];  // [buf][K | V]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the diagonal tests below are scalar branches
   const int hi = lane >> 5;
 
   // ---- block -> (kv head, q tile, head of the group): XCD-contiguous virtual index ------------------
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
   auto issue_loads = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t off = (int64_t)sl[i] * p.kv_stride_tok + head_off;
+      const int64_t off = slot_offset(sl[i], p.kv_stride_tok) + head_off;
       kreg[i] = ldg16(p.k + off);
       vreg[i] = ldg16(p.v + off);
     }
@@ -380,13 +389,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
     if (ntiles > 1) load_slots(1);
   }
   for (int kt = 0; kt < ntiles; ++kt) {
-    char* buf = lds + (kt & 1) * (2 * kTileBytes);
-    write_lds(buf);  // tile kt (its loads were issued one tile ago); the buffer was last read at tile kt-2
-    if (kt + 1 < ntiles) {
+    char* buf = lds + ((ABL & 1) ? 0 : (kt & 1)) * (2 * kTileBytes);
+    if (!(ABL & 1) || kt == 0) write_lds(buf);  // tile kt (its loads were issued one tile ago); the buffer was last read at tile kt-2
+    if (kt + 1 < ntiles && !(ABL & 1)) {
       issue_loads();  // tile kt+1: in flight during this tile's MFMAs
       if (kt + 2 < ntiles) load_slots(kt + 2);
     }
-    __syncthreads();
+    if (!(ABL & 16) || kt == 0) __syncthreads();
 
     const int key0 = kt * kKTile;
     if (key0 > diag + q0 + wave * 32 + 31) continue;  // whole tile above this wave's diagonal
@@ -398,79 +407,90 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
       const int key = kb * 32 + (lane & 31);
+      if (!(ABL & 2)) {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const U4 a = *reinterpret_cast<const U4*>(buf + k_off(key, ks * 32 + hi * 16));
-        s[kb] = mfma32<T>(a, qf[ks], s[kb]);
+        for (int ks = 0; ks < 8; ++ks) {
+          const U4 a = *reinterpret_cast<const U4*>(buf + k_off(key, ks * 32 + hi * 16));
+          s[kb] = mfma32<T>(a, qf[ks], s[kb]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = __uint_as_float(qf[r & 7].x) * 1e-30f + (float)kt;
       }
     }
     // ---- mask, online softmax (lane-local row); kFold: the softmax scale folded into the exponent's fma
-    float tmax = kNegBigP;
-    float m_new, alpha, rsum = 0.f;
-    const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
-    if constexpr (!kFold) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = s[kb][r] * p.scale_log2;
-          if (need_mask) {
-            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key > my_qpos) x = -INFINITY;
-          }
-          s[kb][r] = x;
-          tmax = fmaxf(tmax, x);
-        }
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      m_new = fmaxf(m_run, tmax);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-          s[kb][r] = e;
-          rsum += e;
-        }
-      }
+    if constexpr (ABL & 4) {  // diagnosis: no softmax arithmetic (p = s as it is)
+      m_run = 0.f;
+      l_run += s[0][0] + s[1][15];
     } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = s[kb][r];
-          if (need_mask) {
-            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key > my_qpos) x = -INFINITY;
+      float tmax = kNegBigP;
+      float m_new, alpha, rsum = 0.f;
+      const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
+      if constexpr (!kFold) {
+  #pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float x = s[kb][r] * p.scale_log2;
+            if (need_mask) {
+              const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (key > my_qpos) x = -INFINITY;
+            }
             s[kb][r] = x;
+            tmax = fmaxf(tmax, x);
           }
-          tmax = fmaxf(tmax, x);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+  #pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+            s[kb][r] = e;
+            rsum += e;
+          }
+        }
+      } else {
+  #pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float x = s[kb][r];
+            if (need_mask) {
+              const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (key > my_qpos) x = -INFINITY;
+              s[kb][r] = x;
+            }
+            tmax = fmaxf(tmax, x);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;  // scale > 0: max commutes with it
+        m_new = fmaxf(m_run, tmax);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+  #pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
+            s[kb][r] = e;
+            rsum += e;
+          }
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;  // scale > 0: max commutes with it
-      m_new = fmaxf(m_run, tmax);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
-          s[kb][r] = e;
-          rsum += e;
-        }
+      rsum += __shfl_xor(rsum, 32, 64);
+      l_run = fmaf(l_run, alpha, rsum);
+      if (!__all(m_new == m_run)) {  // alpha == 1 on every row otherwise: the rescale would be the identity
+  #pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
       }
+      m_run = m_new;
     }
-    rsum += __shfl_xor(rsum, 32, 64);
-    l_run = fmaf(l_run, alpha, rsum);
-    if (!__all(m_new == m_run)) {  // alpha == 1 on every row otherwise: the rescale would be the identity
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
-    }
-    m_run = m_new;
 
+    if constexpr (!(ABL & 8)) {
     // ---- O^T += V^T . P^T ------------------------------------------------------------------
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -495,9 +515,639 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
         }
       }
     }
+    } else {
+      o[0][0] += s[0][3] + s[1][7];
+    }
   }
 
   // ---- epilogue: O[q row][d] = O^T / l ---------------------------------------------------------
+  if (q_valid) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = nb * 32 + 8 * rg + 4 * hi;
+        uint2 w;
+        w.x = Elem<T>::pack(o[nb][4 * rg + 0] * inv, o[nb][4 * rg + 1] * inv);
+        w.y = Elem<T>::pack(o[nb][4 * rg + 2] * inv, o[nb][4 * rg + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = w;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Third-generation kernel (impl 4, the default): the math, fragment ownership and LDS images of the tr-read kernel, with
+//   * K/V tiles moved global -> LDS by the DMA path (global_load_lds_dwordx4): no staging registers, no ds_write, no
+//     LDS-write bandwidth.  A wave instruction fills 1 KB = 4 key rows lane-linearly, so the XOR swizzles of the images
+//     are applied on the SOURCE side: the lane that lands on 16-byte slot c of row r fetches piece c ^ swz(r);
+//   * the tile loop unrolled by two: every LDS address is (a per-lane register computed once) + an immediate;
+//   * the causal mask hoisted out of the per-element path (one uniform branch per tile; compare against inline constants);
+//   * one barrier per tile as before: wait own DMA of tile t, barrier, issue the DMA of tile t+1 into the buffer
+//     everyone has just finished reading, compute tile t;
+//   * LDS reads issued >= 4 MFMAs ahead of their use (pinned with sched_barrier), MFMA blocks at s_setprio 1.
+// ABL (diagnosis, wrong results): 1 = tiles DMA'd once, 2 = no QK^T, 4 = no softmax, 8 = no PV.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <typename T, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const PrefillParams p, int total_tiles) {
+  // two distinct LDS objects, not one array: the compiler then knows a tile's fragment reads cannot alias the DMA writes
+  // of the next tile (other object) and does not wait for them (vmcnt) before the reads
+  __shared__ __attribute__((aligned(1024))) char lds_a[2 * kTileBytes];  // tiles 0, 2, ..: [K | V]
+  __shared__ __attribute__((aligned(1024))) char lds_b[2 * kTileBytes];  // tiles 1, 3, ..
+
+  // the MFMA blocks run at priority 1: of two waves of a SIMD the one that has matrix work issues first, the other one's
+  // softmax arithmetic fills in (+5..10 %, tools/prefill_ablate.py; ABL bit 16 switches it off, bit 32 inverts it)
+  constexpr bool kPrioMatrix = !(ABL & 16) && !(ABL & 32);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+
+  const int n_per = (int)(gridDim.x >> 3);
+  const int vidx = (int)(blockIdx.x & 7) * n_per + (int)(blockIdx.x >> 3);
+  if (vidx >= total_tiles * p.hq) return;
+  const int per_kv = total_tiles * p.group;
+  const int kvh = vidx / per_kv;
+  const int rem = vidx - kvh * per_kv;
+  const int ti = rem / p.group;
+  const int hq = kvh * p.group + (rem - ti * p.group);
+  const int tile = p.tile_order ? p.tile_order[ti] : ti;
+
+  int lo = 0, hi_b = p.batch;
+  while (hi_b - lo > 1) {
+    const int mid = (lo + hi_b) >> 1;
+    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
+  }
+  const int b = lo;
+  const int q_begin = p.cu_q[b];
+  const int q_len = p.cu_q[b + 1] - q_begin;
+  const int k_len = p.seq_lens[b];
+  const int q0 = (tile - p.tile_cu[b]) * kQTile;
+  const int row = p.req_rows ? p.req_rows[b] : b;
+  const int* pt = p.page_table + (int64_t)row * p.pt_stride;
+  const int diag = k_len - q_len;
+  const int kend = min(k_len, diag + min(q0 + kQTile, q_len));
+  const int ntiles = (kend + kKTile - 1) / kKTile;
+
+  const int my_q = q0 + wave * 32 + (lane & 31);
+  const bool q_valid = my_q < q_len;
+  const int64_t q_tok = q_begin + (q_valid ? my_q : q_len - 1);
+  U4 qf[8];
+  {
+    const uint16_t* qp = p.q + q_tok * p.q_stride + (int64_t)hq * kD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = ldg16(qp + ks * 16);
+  }
+  const int my_qpos = diag + my_q;
+  const int wave_min_qpos = diag + q0 + wave * 32;  // scalar
+
+  f32x16 o[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+  float m_run = kNegBigP, l_run = 0.f;
+
+  // ---- staging: DMA instruction i of this wave fills rows 16 i + 4 wave .. + 3 (chunk 4 i + wave of the image);
+  //      lane -> row st_row + 16 i, 16-byte slot (lane & 15)
+  const int st_row = tid >> 4;
+  const int64_t k_lane = (int64_t)kvh * p.kv_stride_head + (((lane & 15) ^ (st_row & 15)) << 3);
+  const int64_t v_lane = (int64_t)kvh * p.kv_stride_head + (((lane & 15) ^ ((st_row & 3) << 2)) << 3);
+  int sl[4];
+  auto load_slots = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sl[i] = pt[min(kt * kKTile + st_row + 16 * i, k_len - 1)];
+  };
+  auto issue_dma = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t off = slot_offset(sl[i], p.kv_stride_tok);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.k + off + k_lane), (lds_void_t*)(buf + (4 * i + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(p.v + off + v_lane),
+                                       (lds_void_t*)(buf + kTileBytes + (4 * i + wave) * 1024), 16, 0, 0);
+    }
+  };
+  // per-lane LDS addresses (buffer 0): K fragment of k-step ks, V^T fragment of d block nb
+  int koff[8], voff[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) koff[ks] = k_off(lane & 31, ks * 32 + hi * 16);
+  {
+    const int j = lane & 15;
+    const int r4 = j >> 2;
+    const int ch = j & 3;
+    const int w = (16 * ((lane >> 4) & 1) + 4 * ch) * 2;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) voff[nb] = kTileBytes + hi * 1024 + r4 * 256 + (((nb ^ r4) & 3) << 6) + w;
+  }
+
+  auto tile_body = [&](auto BUFC, const int kt) {
+    constexpr int BUF = decltype(BUFC)::value;
+    char* buf = BUF ? lds_b : lds_a;
+    char* nxt = BUF ? lds_a : lds_b;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (and the slots of tile kt + 1/2)
+    __syncthreads();                                  // everyone's pieces; everyone done with the other buffer
+    if (!(ABL & 1) && kt + 1 < ntiles) {
+      issue_dma(nxt);
+      if (kt + 2 < ntiles) load_slots(kt + 2);
+    }
+    const int key0 = kt * kKTile;
+    if (key0 > wave_min_qpos + 31) return;  // whole tile above this wave's diagonal
+
+    // ---- S^T = K . Q^T.  Issue order is pinned (sched_barrier): the 8 fragments of key block 0 first, then one
+    //      MFMA per further LDS read -- key block 1's fragments under block 0's chain, the V^T fragments of the first
+    //      half of P.V (they do not depend on the softmax) under block 1's chain: no MFMA waits on a read issued just
+    //      before it
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    if constexpr (kPrioMatrix) __builtin_amdgcn_s_setprio(1);
+    if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);
+    U4 vfa[8];  // V^T fragments of keys 0..31: [half][nb]
+    constexpr int kUnitBytes = 4 * 256;
+    auto read_vf = [&](int kb, int half, int nb) {
+      const int ub = (kb * 8 + half * 4) * kUnitBytes;
+      const uint2 v1 = tr_read_b64(buf + voff[nb] + ub);
+      const uint2 v2 = tr_read_b64(buf + voff[nb] + ub + 2 * kUnitBytes);
+      U4 vf;
+      vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
+      return vf;
+    };
+    if constexpr (!(ABL & 2)) {
+      U4 kf0[8], kf1[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kf0[ks] = *reinterpret_cast<const U4*>(buf + koff[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {  // every read is issued >= 4 MFMAs (128 cycles) ahead of its use
+        s[0] = mfma32<T>(kf0[ks], qf[ks], s[0]);
+        if (ks < 4) {
+          kf1[2 * ks] = *reinterpret_cast<const U4*>(buf + koff[2 * ks] + 8192);
+          kf1[2 * ks + 1] = *reinterpret_cast<const U4*>(buf + koff[2 * ks + 1] + 8192);
+        } else if constexpr (!(ABL & 8)) {
+          vfa[ks - 4] = read_vf(0, 0, ks - 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        s[1] = mfma32<T>(kf1[ks], qf[ks], s[1]);
+        if constexpr (!(ABL & 8)) {
+          if (ks < 4) vfa[4 + ks] = read_vf(0, 1, ks);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = __uint_as_float(qf[r & 7].x) * 1e-30f + (float)kt;
+      if constexpr (!(ABL & 8)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vfa[j] = read_vf(0, j >> 2, j & 3);
+      }
+    }
+    if constexpr (kPrioMatrix) __builtin_amdgcn_s_setprio(0);
+    if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(1);
+    if constexpr (ABL & 4) {
+      m_run = 0.f;
+      l_run += s[0][0] + s[1][15];
+    } else {
+      // ---- causal mask (tiles crossing this wave's diagonal only): key0 + c + 4 hi > my_qpos  <=>  c > thr
+      if (key0 + kKTile - 1 > wave_min_qpos) {
+        const int thr = my_qpos - key0 - 4 * hi;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kb * 32 + (r & 3) + 8 * (r >> 2) > thr) s[kb][r] = -INFINITY;
+      }
+      // ---- online softmax, lane-local row (+ lane ^ 32); the scale is folded into the exponent's fma
+      float tmax = kNegBigP;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float rsum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
+          s[kb][r] = e;
+          rsum += e;
+        }
+      rsum += __shfl_xor(rsum, 32, 64);
+      l_run = fmaf(l_run, alpha, rsum);
+      if (!__all(m_new == m_run)) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+      }
+      m_run = m_new;
+    }
+    // ---- O^T += V^T . P^T: keys 0..31 on the fragments read during QK^T, the fragments of keys 32..63 read under them
+    if constexpr (!(ABL & 8)) {
+      auto pack_p = [&](int kb, int half) {
+        U4 pf;
+        pf.x = Elem<T>::pack(s[kb][8 * half + 0], s[kb][8 * half + 1]);
+        pf.y = Elem<T>::pack(s[kb][8 * half + 2], s[kb][8 * half + 3]);
+        pf.z = Elem<T>::pack(s[kb][8 * half + 4], s[kb][8 * half + 5]);
+        pf.w = Elem<T>::pack(s[kb][8 * half + 6], s[kb][8 * half + 7]);
+        return pf;
+      };
+      U4 vfb[8];
+      const U4 p00 = pack_p(0, 0), p01 = pack_p(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kPrioMatrix) __builtin_amdgcn_s_setprio(1);
+      if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j & 3] = mfma32<T>(vfa[j], (j >> 2) ? p01 : p00, o[j & 3]);
+        if (j < 4) {
+          vfb[2 * j] = read_vf(1, (2 * j) >> 2, (2 * j) & 3);
+          vfb[2 * j + 1] = read_vf(1, (2 * j + 1) >> 2, (2 * j + 1) & 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const U4 p10 = pack_p(1, 0), p11 = pack_p(1, 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j & 3] = mfma32<T>(vfb[j], (j >> 2) ? p11 : p10, o[j & 3]);
+      if constexpr (kPrioMatrix) __builtin_amdgcn_s_setprio(0);
+    } else {
+      o[0][0] += s[0][3] + s[1][7];
+    }
+  };
+
+  if (ntiles > 0) {
+    load_slots(0);
+    issue_dma(lds_a);
+    if (ntiles > 1) load_slots(1);
+  }
+  for (int kt = 0; kt < ntiles; kt += 2) {
+    tile_body(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < ntiles) tile_body(std::integral_constant<int, 1>{}, kt + 1);
+  }
+
+  if (q_valid) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = nb * 32 + 8 * rg + 4 * hi;
+        uint2 w;
+        w.x = Elem<T>::pack(o[nb][4 * rg + 0] * inv, o[nb][4 * rg + 1] * inv);
+        w.y = Elem<T>::pack(o[nb][4 * rg + 2] * inv, o[nb][4 * rg + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d) = w;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fourth-generation kernel (impl 5): two wave groups in counter-phase.  One workgroup = 8 waves = a 256-row query tile of
+// one (request, q head); waves w and w + 4 share a SIMD.  Every wave runs the same loop over 64-key tiles t,
+//   MATRIX segment   M(t) = [O^T += V^T(t-1) . P^T(t-1)] then [S^T(t) = K(t) . Q^T]      (32 MFMAs, LDS fragment reads)
+//   s_barrier
+//   SOFTMAX segment  S(t) = mask, row max, exp2, row sum, O rescale, pack P(t)            (VALU only)
+//   s_barrier
+// but group B (waves 4-7) passes one extra barrier before its first segment (and group A one after its last), so B runs
+// one phase behind A:
+//     phase 2t    A: M(t)      B: S(t-1)
+//     phase 2t+1  A: S(t)      B: M(t)
+// and on every SIMD one wave's MFMAs run beside the other wave's softmax arithmetic -- by construction, not by the luck
+// of how two independent workgroups drift (the 2-workgroups-per-CU kernels above co-execute VALU under only 27 % of
+// their MFMA cycles: rocprofv3 SQ_VALU_MFMA_COEXEC_CYCLES, profiles/).  Both segments cost ~1000 cycles.
+//   * rows: wave w of group g owns rows 32 (2 w + g) .. + 31 of the tile, so the causal work of the two groups is equal;
+//   * K/V tiles come by DMA (global_load_lds_dwordx4, source-side swizzle as in impl 4), every wave moving 1/8 of
+//     K(t+2) and V(t+1) at the top of its period t and waiting for them at the end of it: a period and more in flight.
+//     Three 16 KB stages each of K and V (96 KB), as six distinct LDS objects so that the compiler sees that a segment's
+//     fragment reads cannot alias the DMA writes in flight; the tile loop is unrolled by three (stage = t mod 3);
+//   * same math, fragment ownership and accumulation order per query row as impl 2/4: results are bit-identical.
+// tile_cu / total_tiles / tile_order are in units of 256-row tiles for this kernel (msgl_attn_prefill_q_tile).
+// ABL (diagnosis, wrong results): 1 = no DMA after the prologue, 2 = no QK^T MFMAs, 4 = no softmax, 8 = no PV MFMAs.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPPRows = 256;
+
+template <typename T, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillParams p, int total_tiles) {
+  __shared__ __attribute__((aligned(1024))) char lds[6 * kTileBytes];  // K(u) at (u mod 3) * 16 KB, V(u) at 48 KB + (u mod 3) * 16 KB
+  // The DMA destination is given to the compiler as an offset from a SECOND, unrelated LDS object: it then sees no
+  // dependence between the DMA writes and the fragment reads of `lds` and adds no s_waitcnt vmcnt of its own in front of
+  // the reads (with six tile images in flight its alias tracking of LDS DMA gives up and waits for everything, i.e. for
+  // the tiles just requested).  Every DMA -> read dependence is ordered by hand: vmcnt(0) + s_barrier below.
+  __shared__ __attribute__((aligned(16))) char dma_anchor[16];
+  uint32_t anchor_to_lds = (uint32_t)(uintptr_t)(lds_char*)lds - (uint32_t)(uintptr_t)(lds_char*)dma_anchor;
+  asm volatile("" : "+s"(anchor_to_lds));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int grp = wave >> 2;
+  const int blk = ((wave & 3) << 1) | grp;
+
+  const int n_per = (int)(gridDim.x >> 3);
+  const int vidx = (int)(blockIdx.x & 7) * n_per + (int)(blockIdx.x >> 3);
+  if (vidx >= total_tiles * p.hq) return;
+  const int per_kv = total_tiles * p.group;
+  const int kvh = vidx / per_kv;
+  const int rem = vidx - kvh * per_kv;
+  const int ti = rem / p.group;
+  const int hq = kvh * p.group + (rem - ti * p.group);
+  const int tile = p.tile_order ? p.tile_order[ti] : ti;
+
+  int lo = 0, hi_b = p.batch;
+  while (hi_b - lo > 1) {
+    const int mid = (lo + hi_b) >> 1;
+    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
+  }
+  const int b = lo;
+  const int q_begin = p.cu_q[b];
+  const int q_len = p.cu_q[b + 1] - q_begin;
+  const int k_len = p.seq_lens[b];
+  const int q0 = (tile - p.tile_cu[b]) * kPPRows;
+  const int row = p.req_rows ? p.req_rows[b] : b;
+  const int* pt = p.page_table + (int64_t)row * p.pt_stride;
+  const int diag = k_len - q_len;
+  const int kend = min(k_len, diag + min(q0 + kPPRows, q_len));
+  const int ntiles = (kend + kKTile - 1) / kKTile;  // of the workgroup (its last rows)
+
+  const int r0 = q0 + blk * 32;
+  const int my_q = r0 + (lane & 31);
+  const bool q_valid = my_q < q_len;
+  const int64_t q_tok = q_begin + (q_valid ? my_q : q_len - 1);
+  U4 qf[8];
+  {
+    const uint16_t* qp = p.q + q_tok * p.q_stride + (int64_t)hq * kD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = ldg16(qp + ks * 16);
+  }
+  const int my_qpos = diag + my_q;
+  const int wave_min_qpos = diag + r0;
+  const int wave_max_qpos = r0 < q_len ? wave_min_qpos + 31 : -1;  // a wave with no row of the request skips every tile
+
+  f32x16 o[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+  float m_run = kNegBigP, l_run = 0.f;
+  f32x16 s[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+  U4 pf[4];  // P(t) packed to 16 bit: [kb][half]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf[i] = U4{0u, 0u, 0u, 0u};
+
+  // ---- staging: this wave fills 1 KB chunks `wave` and `wave + 8` of a tile image (rows 4 wave .. + 3 and + 32)
+  const int st_row = 4 * wave + (lane >> 4);
+  const int64_t k_lane = (int64_t)kvh * p.kv_stride_head + (((lane & 15) ^ (st_row & 15)) << 3);
+  const int64_t v_lane = (int64_t)kvh * p.kv_stride_head + (((lane & 15) ^ ((st_row & 3) << 2)) << 3);
+  int sl[3][2];  // page-table slots of this lane's two rows: tile u in sl[u mod 3] (tiles t + 1, t + 2, t + 3 during period t)
+  auto load_slots = [&](int kt, int (&sl)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) sl[i] = pt[min(kt * kKTile + st_row + 32 * i, k_len - 1)];
+  };
+  auto dma_piece = [&](const uint16_t* base, int64_t lane_off, int slot, int img, int i) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + slot_offset(slot, p.kv_stride_tok) + lane_off),
+                                     (lds_void_t*)((lds_char*)dma_anchor + (anchor_to_lds + img + (wave + 8 * i) * 1024)), 16, 0, 0);
+  };
+  int koff[8], voff[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) koff[ks] = k_off(lane & 31, ks * 32 + hi * 16);
+  {
+    const int j = lane & 15;
+    const int r4 = j >> 2;
+    const int ch = j & 3;
+    const int w = (16 * ((lane >> 4) & 1) + 4 * ch) * 2;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) voff[nb] = hi * 1024 + r4 * 256 + (((nb ^ r4) & 3) << 6) + w;
+  }
+  constexpr int kUnitBytes = 4 * 256;
+
+  // diagnosis: s_memtime stamps of periods 8..23 of the first 32 workgroups: [wg][wave][period - 8][16]
+  unsigned long long* const trace_row = (ABL & 128) && p.trace && vidx < 32 && lane == 0 ? p.trace + ((int64_t)vidx * 8 + wave) * 256 : nullptr;
+  auto stamp = [&](int kt, int k) __attribute__((always_inline)) {
+    if constexpr (ABL & 128) {
+      if (trace_row && kt >= 8 && kt < 24) trace_row[(kt - 8) * 16 + k] = __builtin_readcyclecounter();
+    }
+  };
+
+  U4 vfp[4];  // V^T fragments of the first four P.V MFMAs of the NEXT matrix segment, read at the end of a softmax segment
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vfp[i] = U4{0u, 0u, 0u, 0u};
+  auto read_vf = [&](const char* vimg, int j) __attribute__((always_inline)) {  // MFMA j of P.V: keys 32 (j >> 3) + 16 ((j >> 2) & 1) .., d block j & 3
+    const int ub = ((j >> 3) * 8 + ((j >> 2) & 1) * 4) * kUnitBytes;
+    const uint2 v1 = tr_read_b64(vimg + voff[j & 3] + ub);
+    const uint2 v2 = tr_read_b64(vimg + voff[j & 3] + ub + 2 * kUnitBytes);
+    U4 vf;
+    vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
+    return vf;
+  };
+  // ---- matrix segment of tile t: P.V of tile t - 1 (image vimg), then QK^T of tile t (image kimg).  Issue order pinned
+  //      (sched_barrier): every LDS read is issued 4 MFMAs ahead of the MFMA that consumes it; the first K fragments are
+  //      requested before P.V starts
+  auto seg_matrix = [&](const char* kimg, const char* vimg, const int kt) __attribute__((always_inline)) {
+    const bool do_pv = kt >= 1 && (kt - 1) * kKTile <= wave_max_qpos;
+    const bool do_qk = kt < ntiles && kt * kKTile <= wave_max_qpos;
+    auto read_kf = [&](int i) __attribute__((always_inline)) {
+      return *reinterpret_cast<const U4*>(kimg + koff[i & 7] + (i >> 3) * 8192);
+    };
+    constexpr auto qk_idx = [](int i) { return (i & 1) * 8 + (i >> 1); };  // MFMA i of QK^T: key block i & 1, k-step i >> 1
+    U4 kf[16];
+    if (do_qk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kf[qk_idx(i)] = read_kf(qk_idx(i));
+    }
+    stamp(kt, 5);
+    if (do_pv) {
+      U4 vf[16];
+      if (grp == 1) {  // requested at the end of this wave's last softmax segment
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vf[j] = vfp[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vf[j] = read_vf(vimg, j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if constexpr (!(ABL & 8)) o[j & 3] = mfma32<T>(vf[j], pf[j >> 2], o[j & 3]);
+        if (j + 4 < 16) vf[j + 4] = read_vf(vimg, j + 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    stamp(kt, 6);
+    if (do_qk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {  // the two key blocks' accumulation chains alternate
+        if constexpr (!(ABL & 2)) s[i & 1] = mfma32<T>(kf[qk_idx(i)], qf[i >> 1], s[i & 1]);
+        if (i + 4 < 16) kf[qk_idx(i + 4)] = read_kf(qk_idx(i + 4));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- softmax segment of tile t: s (scores) -> pf (probabilities, 16 bit), running max / sum, O rescale.  Carries this
+  //      wave's DMA pieces of K(t+2) -> kdst and V(t+1) -> vdst between its blocks (a VMEM issue among VALU work costs
+  //      least: issued back to back at the top of the matrix segment the eight waves' pieces held the MFMAs up for
+  //      ~1300 cycles per period, tools/prefill_trace.py), and (group B) ends by requesting the first V^T fragments of
+  //      the next matrix segment from V(t) (vnext)
+  auto seg_softmax = [&](auto RC, const int kt, int kdst, int vdst, const char* vnext) __attribute__((always_inline)) {
+    constexpr int R = decltype(RC)::value;
+    const bool act = kt < ntiles && kt * kKTile <= wave_max_qpos;
+    const bool dk = !(ABL & 1) && kt + 2 < ntiles, dv = !(ABL & 1) && kt + 1 < ntiles;
+    float m_new = m_run, alpha = 1.f, rsum = 0.f;
+    if (act && !(ABL & 4)) {
+      const int key0 = kt * kKTile;
+      if (key0 + kKTile - 1 > wave_min_qpos) {  // the tile crosses this wave's diagonal: key0 + c + 4 hi > my_qpos <=> c > thr
+        const int thr = my_qpos - key0 - 4 * hi;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kb * 32 + (r & 3) + 8 * (r >> 2) > thr) s[kb][r] = -INFINITY;
+      }
+      float tmax = kNegBigP;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;
+      m_new = fmaxf(m_run, tmax);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    }
+    stamp(kt, 8);
+    if (dk) dma_piece(p.k, k_lane, sl[(R + 2) % 3][0], kdst, 0);
+    stamp(kt, 9);
+    if (act && !(ABL & 4)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[0][r], p.scale_log2, -m_new));
+        s[0][r] = e;
+        rsum += e;
+      }
+    }
+    stamp(kt, 10);
+    if (dk) dma_piece(p.k, k_lane, sl[(R + 2) % 3][1], kdst, 1);
+    stamp(kt, 11);
+    if (act && !(ABL & 4)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[1][r], p.scale_log2, -m_new));
+        s[1][r] = e;
+        rsum += e;
+      }
+    }
+    stamp(kt, 12);
+    if (dv) dma_piece(p.v, v_lane, sl[(R + 1) % 3][0], vdst, 0);
+    stamp(kt, 13);
+    if (act) {
+      if constexpr (ABL & 4) {
+        l_run += s[0][0] + s[1][15];
+        m_run = 0.f;
+      } else {
+        rsum += __shfl_xor(rsum, 32, 64);
+        l_run = fmaf(l_run, alpha, rsum);
+        if (!__all(m_new == m_run)) {
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
+        }
+        m_run = m_new;
+      }
+    }
+    stamp(kt, 14);
+    if (dv) dma_piece(p.v, v_lane, sl[(R + 1) % 3][1], vdst, 1);
+    stamp(kt, 15);
+    if (!(ABL & 1) && kt + 3 < ntiles) load_slots(kt + 3, sl[R]);  // its old content (tile t) is dead
+    if (act) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          U4 w;
+          w.x = Elem<T>::pack(s[kb][8 * half + 0], s[kb][8 * half + 1]);
+          w.y = Elem<T>::pack(s[kb][8 * half + 2], s[kb][8 * half + 3]);
+          w.z = Elem<T>::pack(s[kb][8 * half + 4], s[kb][8 * half + 5]);
+          w.w = Elem<T>::pack(s[kb][8 * half + 6], s[kb][8 * half + 7]);
+          pf[kb * 2 + half] = w;
+        }
+      // group B only: in group A's softmax segment (one phase earlier) group B's pieces of V(t) may still be in flight
+      if (grp == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vfp[j] = read_vf(vnext, j);
+      }
+    }
+  };
+
+  // one period of tile t; R = t mod 3: K(u) lives in k[u mod 3], V(u) in v[u mod 3]
+  auto period = [&](auto RC, const int kt) __attribute__((always_inline)) {
+    constexpr int R = decltype(RC)::value;
+    constexpr int kimg[3] = {0, kTileBytes, 2 * kTileBytes};
+    constexpr int vimg[3] = {3 * kTileBytes, 4 * kTileBytes, 5 * kTileBytes};
+    stamp(kt, 0);
+    if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(0);
+    if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(1);
+    seg_matrix(lds + kimg[R], lds + vimg[(R + 2) % 3], kt);
+    stamp(kt, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the pieces of K(t+1), V(t) this wave sent off in its last softmax segment have landed
+    stamp(kt, 7);
+    asm volatile("s_barrier" ::: "memory");
+    stamp(kt, 2);
+    if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(1);
+    if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);
+    seg_softmax(RC, kt, kimg[(R + 2) % 3], vimg[(R + 1) % 3], lds + vimg[R]);
+    stamp(kt, 3);
+    asm volatile("s_barrier" ::: "memory");
+  };
+
+  if (ntiles > 0) {
+    // prologue: K(0), V(0), K(1) with the slots of tiles 0 and 1; slots of tile 2
+    load_slots(0, sl[0]);
+    load_slots(ntiles > 1 ? 1 : 0, sl[1]);
+    load_slots(ntiles > 2 ? 2 : 0, sl[2]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma_piece(p.k, k_lane, sl[0][i], 0, i);
+      dma_piece(p.v, v_lane, sl[0][i], 3 * kTileBytes, i);
+      if (ntiles > 1) dma_piece(p.k, k_lane, sl[1][i], kTileBytes, i);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_barrier" ::: "memory");
+    if constexpr (ABL & 64) { if (grp == 1) __builtin_amdgcn_s_setprio(1); }
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");  // group B: one phase behind
+    for (int kt = 0; kt <= ntiles; kt += 3) {  // periods 0 .. ntiles (the last one only finishes P.V of the last tile)
+      period(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 <= ntiles) period(std::integral_constant<int, 1>{}, kt + 1);
+      if (kt + 2 <= ntiles) period(std::integral_constant<int, 2>{}, kt + 2);
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+  }
+
   if (q_valid) {
     const float inv = 1.0f / l_run;
     uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
@@ -519,6 +1169,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
 
 using namespace msgl;
 
+static unsigned long long* g_prefill_trace = nullptr;
+// diagnosis: device buffer of 32 * 8 * 256 uint64 for the clock stamps of impl 5 + 128 (nullptr: off)
+extern "C" int msgl_attn_prefill_trace(void* stamps) {
+  g_prefill_trace = static_cast<unsigned long long*>(stamps);
+  return MSGL_OK;
+}
+
+extern "C" int msgl_attn_prefill_q_tile(int impl) { return (impl == 5 || (impl >= 128 && impl < 512)) ? kPPRows : kQTile; }
+
 extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
                                  const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
                                  const int32_t* seq_lens, const int32_t* cu_seqlens_q, const int32_t* tile_cu,
@@ -527,13 +1186,15 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
                                  int64_t out_stride_tok, float sm_scale, int dtype, const int32_t* tile_order,
                                  int impl, void* stream) {
   MSGL_REQUIRE(batch >= 0 && total_tiles >= 0, "attn_prefill: negative sizes");
-  MSGL_REQUIRE(impl >= 0 && impl <= 3, "attn_prefill: impl %d (0 default, 1 register-transposed V, 2 tr-read, 3 tr-read unfolded scale)", impl);
+  MSGL_REQUIRE((impl >= 0 && impl <= 5) || (impl >= 16 && impl <= 48) || (impl >= 64 && impl < 512),
+               "attn_prefill: impl %d (0 default, 1 register-transposed V, 2 tr-read, 3 tr-read unfolded scale, 16 + bits: ablations)", impl);
   if (batch == 0 || total_tiles == 0) return MSGL_OK;
   MSGL_REQUIRE(out && q && k_cache && v_cache && page_table && seq_lens && cu_seqlens_q && tile_cu,
                "attn_prefill: null pointer");
   MSGL_REQUIRE(head_dim == 128, "attn_prefill: head_dim %d unsupported (128 only)", head_dim);
   MSGL_REQUIRE(num_kv_heads >= 1 && num_q_heads % num_kv_heads == 0 && num_q_heads <= 65535,
                "attn_prefill: %d q heads / %d kv heads", num_q_heads, num_kv_heads);
+  MSGL_REQUIRE(kv_stride_tok > 0 && kv_stride_tok < (1ll << 32), "attn_prefill: kv token stride %lld", (long long)kv_stride_tok);
   MSGL_REQUIRE(q_stride_tok % 8 == 0 && kv_stride_tok % 8 == 0 && kv_stride_head % 8 == 0 &&
                    out_stride_tok % 4 == 0,
                "attn_prefill: strides must be multiples of 8 elements");
@@ -560,12 +1221,13 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
   p.hq = num_q_heads;
   p.group = num_q_heads / num_kv_heads;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.trace = g_prefill_trace;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != MSGL_BF16 && dtype != MSGL_FP16) {
     set_error("attn_prefill: unsupported dtype code %d", dtype);
     return MSGL_EINVAL;
   }
-  if (impl == 0) impl = 2;  // the tr-read kernel; impl 1 keeps the first-generation kernel callable (cross-check in tests)
+  if (impl == 0) impl = 4;  // the DMA-staged kernel; impl 1, 2, 3 keep the earlier generations callable (cross-checks in tests)
   if (impl == 1) {  // first-generation kernel: 2-D grid in natural order (tile_order unused)
     const dim3 grid((unsigned)total_tiles, (unsigned)num_q_heads), block(256);
     if (dtype == MSGL_BF16) attn_prefill_kernel<BF16><<<grid, block, 0, s>>>(p);
@@ -574,7 +1236,41 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
     const int64_t total = (int64_t)total_tiles * num_q_heads;
     MSGL_REQUIRE(total < (1ll << 30), "attn_prefill: %lld workgroups", (long long)total);
     const unsigned blocks = (unsigned)((total + 7) / 8) * 8;  // 8 XCDs x n_per
-    if (impl == 3) {
+    if (impl == 5 || (impl >= 128 && impl < 512)) {  // counter-phase kernel (256-row tiles); 128 + bits: its ablations
+      const int abl = impl == 5 ? 0 : impl - 128;
+      MSGL_REQUIRE(abl == 0 || dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
+#define MSGL_PF_PP(A) case A: attn_prefill_pp_kernel<BF16, A><<<dim3(blocks), dim3(512), 0, s>>>(p, total_tiles); break
+      if (dtype == MSGL_FP16) attn_prefill_pp_kernel<FP16><<<dim3(blocks), dim3(512), 0, s>>>(p, total_tiles);
+      else switch (abl) {
+        MSGL_PF_PP(0); MSGL_PF_PP(1); MSGL_PF_PP(2); MSGL_PF_PP(4); MSGL_PF_PP(8); MSGL_PF_PP(10); MSGL_PF_PP(14); MSGL_PF_PP(15); MSGL_PF_PP(11); MSGL_PF_PP(5); MSGL_PF_PP(16); MSGL_PF_PP(32); MSGL_PF_PP(64); MSGL_PF_PP(128); MSGL_PF_PP(129); MSGL_PF_PP(132); MSGL_PF_PP(136); MSGL_PF_PP(138);
+        default: set_error("attn_prefill: unknown ablation %d", abl); return MSGL_EINVAL;
+      }
+#undef MSGL_PF_PP
+    } else if (impl == 4 || (impl >= 64 && impl < 128)) {  // DMA-staged kernel; 64 + bits: its ablations
+      const int abl = impl == 4 ? 0 : impl - 64;
+      MSGL_REQUIRE(abl == 0 || dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
+#define MSGL_PF_DMA(A) case A: attn_prefill_dma_kernel<BF16, A><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles); break
+      if (dtype == MSGL_FP16) attn_prefill_dma_kernel<FP16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+      else switch (abl) {
+        MSGL_PF_DMA(0); MSGL_PF_DMA(1); MSGL_PF_DMA(2); MSGL_PF_DMA(4); MSGL_PF_DMA(8); MSGL_PF_DMA(6); MSGL_PF_DMA(12);
+        MSGL_PF_DMA(10); MSGL_PF_DMA(14); MSGL_PF_DMA(15); MSGL_PF_DMA(16); MSGL_PF_DMA(32);
+        default: set_error("attn_prefill: unknown ablation %d", abl); return MSGL_EINVAL;
+      }
+#undef MSGL_PF_DMA
+    } else if (impl == 48) {  // diagnosis: the default kernel at ONE workgroup per CU (40 KB of unused dynamic LDS on top of its 64)
+      MSGL_REQUIRE(dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_tr_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 40 << 10);
+      attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 40 << 10, s>>>(p, total_tiles);
+    } else if (impl >= 16 && impl < 48) {  // diagnosis: ablation bits = impl - 16
+#define MSGL_PF_ABL(A) case A: attn_prefill_tr_kernel<BF16, true, A><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles); break
+      MSGL_REQUIRE(dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
+      switch (impl - 16) {
+        MSGL_PF_ABL(1); MSGL_PF_ABL(2); MSGL_PF_ABL(4); MSGL_PF_ABL(8); MSGL_PF_ABL(6); MSGL_PF_ABL(10); MSGL_PF_ABL(12);
+        MSGL_PF_ABL(14); MSGL_PF_ABL(15); MSGL_PF_ABL(17); MSGL_PF_ABL(31); MSGL_PF_ABL(16);
+        default: set_error("attn_prefill: unknown ablation %d", impl - 16); return MSGL_EINVAL;
+      }
+#undef MSGL_PF_ABL
+    } else if (impl == 3) {
       if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16, false><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
       else attn_prefill_tr_kernel<FP16, false><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
     } else if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);

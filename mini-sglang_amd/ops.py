@@ -356,13 +356,26 @@ def attn_decode_select(impl: int) -> None:
     check(lib().msgl_attn_decode_select(int(impl)), "attn_decode_select")
 
 
+PREFILL_IMPL = int(os.environ.get("MSGL_PREFILL_IMPL", "0"))  # 0 = the library's default kernel (include/msgl_hip.h)
+
+
+def prefill_q_tile(impl: Optional[int] = None) -> int:
+    """Query rows per tile of the prefill kernel behind `impl` (None: the process default): the unit of tile_cu,
+    total_tiles and tile_order."""
+    return int(lib().msgl_attn_prefill_q_tile(PREFILL_IMPL if impl is None else int(impl)))
+
+
 def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                  page_table: torch.Tensor, req_rows: Optional[torch.Tensor], seq_lens: torch.Tensor,
                  cu_seqlens_q: torch.Tensor, tile_cu: torch.Tensor, batch: int, total_tiles: int,
-                 sm_scale: float, tile_order: Optional[torch.Tensor] = None, impl: int = 0) -> None:
-    """tile_order: optional int32 [total_tiles] schedule of the q tiles (heaviest first); impl: 0 default,
-    1 first-generation kernel, 2 tr-read kernel, 3 tr-read kernel with gen-1's softmax arithmetic (include/msgl_hip.h)."""
+                 sm_scale: float, tile_order: Optional[torch.Tensor] = None, impl: Optional[int] = None) -> None:
+    """tile_order: optional int32 [total_tiles] schedule of the q tiles (heaviest first); impl: None = process default
+    (PREFILL_IMPL), 0 library default, 1 first-generation kernel, 2 tr-read kernel, 3 tr-read kernel with gen-1's softmax
+    arithmetic, 4 DMA-staged, 5 counter-phase kernel (include/msgl_hip.h).  tile_cu / total_tiles / tile_order are in
+    units of prefill_q_tile(impl) query rows."""
     _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, cu_seqlens_q, tile_cu)
+    if impl is None:
+        impl = PREFILL_IMPL
     if tile_order is not None:
         _need_cuda(tile_order)
         assert tile_order.dtype == torch.int32 and tile_order.is_contiguous() and tile_order.numel() == total_tiles

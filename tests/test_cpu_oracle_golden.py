@@ -77,18 +77,19 @@ def test_product_metadata_host_buffer_matches_reference(golden_dir):
         k = np.array([s[2] for s in specs], dtype=np.int64)
         bs = len(specs)
         decode = int(q.max()) == 1
-        tiles = (q + _lib.PREFILL_QTILE - 1) // _lib.PREFILL_QTILE
-        total = 0 if decode else int(tiles.sum())
-        h = np.full(4 * bs + 2 + total, -7, dtype=np.int32)
-        fill_metadata_host(h, q, k, rows, decode)
-        assert np.array_equal(h[:bs], c["cache_seqlens"].numpy()), name
-        assert np.array_equal(h[bs: 2 * bs], rows), name
-        assert np.array_equal(h[2 * bs: 3 * bs + 1], c["cu_seqlens_q"].numpy()), name
-        assert np.array_equal(h[2 * bs + 1: 3 * bs + 1] - 1, c["last_indices"].numpy()), name
-        if not decode:
-            assert h[3 * bs + 1] == 0 and np.array_equal(np.diff(h[3 * bs + 1: 4 * bs + 2]), tiles), name
-            order = h[4 * bs + 2:]
-            assert sorted(order.tolist()) == list(range(total)), name  # a permutation of the q tiles
+        for qt in (_lib.PREFILL_QTILE, 256):  # rows per q tile: the 4-wave kernels' and the counter-phase kernel's
+            tiles = (q + qt - 1) // qt
+            total = 0 if decode else int(tiles.sum())
+            h = np.full(4 * bs + 2 + total, -7, dtype=np.int32)
+            fill_metadata_host(h, q, k, rows, decode, qt)
+            assert np.array_equal(h[:bs], c["cache_seqlens"].numpy()), name
+            assert np.array_equal(h[bs: 2 * bs], rows), name
+            assert np.array_equal(h[2 * bs: 3 * bs + 1], c["cu_seqlens_q"].numpy()), name
+            assert np.array_equal(h[2 * bs + 1: 3 * bs + 1] - 1, c["last_indices"].numpy()), name
+            if not decode:
+                assert h[3 * bs + 1] == 0 and np.array_equal(np.diff(h[3 * bs + 1: 4 * bs + 2]), tiles), name
+                order = h[4 * bs + 2:]
+                assert sorted(order.tolist()) == list(range(total)), name  # a permutation of the q tiles
 
 
 def test_prefill_tile_order_is_heaviest_first():

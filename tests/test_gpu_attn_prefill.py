@@ -53,9 +53,10 @@ def build(g, specs, hq, hkv, page_size, dtype=torch.bfloat16):
                 hkv=hkv)
 
 
-@pytest.fixture(params=[2, 1], ids=["tr_read", "gen1"])
+@pytest.fixture(params=[0, 5, 2, 1], ids=["default_dma", "counter_phase", "tr_read", "gen1"])
 def impl(request):
-    """Both kernel generations (include/msgl_hip.h: impl 2 = ds_read_b64_tr_b16 kernel, the default; 1 = first one)."""
+    """Every kernel generation (include/msgl_hip.h: 0 = the default = impl 4, DMA-staged; 5 = counter-phase wave groups on
+    256-row tiles; 2 = ds_read_b64_tr_b16 kernel; 1 = the first one)."""
     return request.param
 
 
@@ -70,13 +71,14 @@ def run(ops, dev, c, impl=0, order="heavy"):
     q = qkv[:, : hq * D].view(T, hq, D)
     out = torch.zeros((T, hq, D), dtype=qkv.dtype, device=dev)
     cu_q = torch.tensor([0] + c["q_lens"], dtype=torch.int32).cumsum(0).to(torch.int32)
-    tiles = [(n + 127) // 128 for n in c["q_lens"]]
+    qt = ops.prefill_q_tile(impl)  # rows per q tile of this kernel: 128, or 256 for the counter-phase kernel
+    tiles = [(n + qt - 1) // qt for n in c["q_lens"]]
     tile_cu = torch.tensor([0] + tiles, dtype=torch.int32).cumsum(0).to(torch.int32)
     tile_order = None
     if order == "heavy":
         tile_order = torch.from_numpy(prefill_tile_order(np.array(c["q_lens"], dtype=np.int64),
                                                          np.array(c["k_lens"], dtype=np.int64),
-                                                         np.array(tiles, dtype=np.int64))).to(dev)
+                                                         np.array(tiles, dtype=np.int64), qt)).to(dev)
     elif order == "reversed":
         tile_order = torch.arange(int(tile_cu[-1]) - 1, -1, -1, dtype=torch.int32, device=dev)
     ops.attn_prefill(out, q, c["k"].to(dev), c["v"].to(dev), c["table"].to(dev),
@@ -120,10 +122,11 @@ def test_prefill_tile_order_does_not_change_results(ops, dev):
     g = torch.Generator().manual_seed(11)
     specs = [(0, 300), (128, 400), (0, 1), (512, 1024), (0, 129)]
     c = build(g, specs, 10, 2, 16)
-    a = run(ops, dev, c, 2, order="heavy")
-    assert torch.equal(a, run(ops, dev, c, 2, order=None))
-    assert torch.equal(a, run(ops, dev, c, 2, order="reversed"))
-    torch.testing.assert_close(a.double(), oracle(c), **TOL)
+    for impl in (0, 2, 5):
+        a = run(ops, dev, c, impl, order="heavy")
+        assert torch.equal(a, run(ops, dev, c, impl, order=None))
+        assert torch.equal(a, run(ops, dev, c, impl, order="reversed"))
+        torch.testing.assert_close(a.double(), oracle(c), **TOL)
 
 
 def test_prefill_generations_agree(ops, dev):
@@ -134,6 +137,14 @@ def test_prefill_generations_agree(ops, dev):
     # the default (scale folded into the exponent's fma) differs from it by rounding only
     assert torch.equal(run(ops, dev, c, 1), run(ops, dev, c, 3))
     torch.testing.assert_close(run(ops, dev, c, 2).float(), run(ops, dev, c, 3).float(), atol=4e-3, rtol=2 ** -7)
+    # the DMA-staged kernel (4, the default) and the counter-phase kernel (5, 256-row tiles, 8 waves) keep impl 2's math,
+    # fragment ownership and accumulation order per query row: identical bits, also on a batch with cache hits, a ragged
+    # tail, a request shorter than one tile and one spanning several 256-row tiles
+    for cc in (c, build(torch.Generator().manual_seed(13), [(0, 1), (0, 255), (0, 257), (300, 1100), (0, 700), (4096, 4200)], 10, 2, 16)):
+        a = run(ops, dev, cc, 2)
+        assert torch.equal(a, run(ops, dev, cc, 4))
+        assert torch.equal(a, run(ops, dev, cc, 0))
+        assert torch.equal(a, run(ops, dev, cc, 5))
 
 
 def test_prefill_long(ops, dev, impl):

@@ -306,7 +306,7 @@ def test_op_chain_one_layer_each_op_on_the_oracles_input(dev):
                            vpd.view(-1, hkv * D), d(out_loc), D)
     got["q_rope"], got["k_rope"] = qg, kg
     assert torch.equal(kpd.cpu()[out_loc.long()].reshape(T, -1), kg.cpu()) and torch.equal(vpd.cpu()[out_loc.long()].reshape(T, -1), v)
-    from mini_sglang_amd._lib import PREFILL_QTILE
+    PREFILL_QTILE = ops.prefill_q_tile()
     tiles = (T + PREFILL_QTILE - 1) // PREFILL_QTILE
     attn = torch.empty((T, hq, D), dtype=torch.bfloat16, device=dev)
     ops.attn_prefill(attn, d(r["q_rope"]).view(T, hq, D), d(kp), d(vp), d(table), torch.zeros(1, dtype=torch.int32, device=dev),

@@ -72,7 +72,7 @@ def decode_case(B, hq, hkv, lens, page_size, dev, dtype=torch.bfloat16, D=128):
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16
 
 
-def prefill_case(q_lens, k_lens, hq, hkv, page_size, dev, dtype=torch.bfloat16, D=128):
+def prefill_case(q_lens, k_lens, hq, hkv, page_size, dev, dtype=torch.bfloat16, D=128, q_tile=128):
     """A prefill batch in a shuffled paged pool: returns the ops.attn_prefill argument tuple + causal flops."""
     import numpy as np
 
@@ -96,10 +96,10 @@ def prefill_case(q_lens, k_lens, hq, hkv, page_size, dev, dtype=torch.bfloat16, 
     q = torch.randn((T, hq, D), device=dev, dtype=dtype)
     out = torch.empty_like(q)
     cu_q = torch.tensor([0] + list(q_lens), dtype=torch.int32).cumsum(0).to(torch.int32).to(dev)
-    tiles = np.array([(n + 127) // 128 for n in q_lens], dtype=np.int64)
+    tiles = np.array([(n + q_tile - 1) // q_tile for n in q_lens], dtype=np.int64)
     tile_cu = torch.tensor([0] + tiles.tolist(), dtype=torch.int32).cumsum(0).to(torch.int32).to(dev)
     order = torch.from_numpy(prefill_tile_order(np.array(q_lens, dtype=np.int64), np.array(k_lens, dtype=np.int64),
-                                                tiles)).to(dev)
+                                                tiles, q_tile)).to(dev)
     seq = torch.tensor(k_lens, dtype=torch.int32, device=dev)
     # flops = 4 Hq D sum_i [q_i (k_i - q_i) + q_i (q_i + 1) / 2]
     flops = 4 * hq * D * sum(qi * (ki - qi) + qi * (qi + 1) // 2 for qi, ki in zip(q_lens, k_lens))
