@@ -70,6 +70,20 @@ __device__ __forceinline__ int64_t slot_offset(int slot, int64_t stride_tok) {
   return (int64_t)((uint64_t)(uint32_t)slot * (uint64_t)(uint32_t)stride_tok);
 }
 
+// request b with tile_cu[b] <= tile < tile_cu[b + 1]: 64 entries per step, one per lane, counted with a ballot -- ONE
+// memory latency for batches up to 64 requests where the bisection paid log2(B) dependent ones (~2 us of a workgroup
+// that computes for ~5 us on the benchmark's prefill chunks)
+__device__ __forceinline__ int find_request(const int* tile_cu, int batch, int tile, int lane) {
+  int base = 0;
+  for (;;) {
+    const int idx = base + lane;
+    const int v = idx < batch ? tile_cu[idx] : 0x7fffffff;
+    const int cnt = __popcll(__ballot(v <= tile));
+    if (cnt < 64 || base + 64 >= batch) return __builtin_amdgcn_readfirstlane(base + cnt - 1);
+    base += 64;
+  }
+}
+
 // swizzles (see header comment): K image [64 keys][256 B], V^T image [128 d][128 B = 64 keys]
 __device__ __forceinline__ int k_off(int key, int byte_in_row) { return key * 256 + (byte_in_row ^ ((key & 15) << 4)); }
 __device__ __forceinline__ int vt_g(int d) { return ((d >> 1) & 15) ^ ((d >> 5) & 3); }
@@ -548,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_tr_kernel(const PrefillPa
 //   * the causal mask hoisted out of the per-element path (one uniform branch per tile; compare against inline constants);
 //   * one barrier per tile as before: wait own DMA of tile t, barrier, issue the DMA of tile t+1 into the buffer
 //     everyone has just finished reading, compute tile t;
-//   * LDS reads issued >= 4 MFMAs ahead of their use (pinned with sched_barrier), MFMA blocks at s_setprio 1.
+//   * LDS reads issued >= 4 MFMAs ahead of their use (pinned with sched_barrier).
 // ABL (diagnosis, wrong results): 1 = tiles DMA'd once, 2 = no QK^T, 4 = no softmax, 8 = no PV.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -561,9 +575,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const PrefillP
   __shared__ __attribute__((aligned(1024))) char lds_a[2 * kTileBytes];  // tiles 0, 2, ..: [K | V]
   __shared__ __attribute__((aligned(1024))) char lds_b[2 * kTileBytes];  // tiles 1, 3, ..
 
-  // the MFMA blocks run at priority 1: of two waves of a SIMD the one that has matrix work issues first, the other one's
-  // softmax arithmetic fills in (+5..10 %, tools/prefill_ablate.py; ABL bit 16 switches it off, bit 32 inverts it)
-  constexpr bool kPrioMatrix = !(ABL & 16) && !(ABL & 32);
+  // ABL bit 16: MFMA blocks at s_setprio 1, bit 32: the softmax at priority 1 instead.  Neither moves the kernel outside
+  // run-to-run noise once the variants are timed interleaved (tools/prefill_ablate.py), so the default sets no priority
+  constexpr bool kPrioMatrix = (ABL & 16) != 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -579,12 +593,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const PrefillP
   const int hq = kvh * p.group + (rem - ti * p.group);
   const int tile = p.tile_order ? p.tile_order[ti] : ti;
 
-  int lo = 0, hi_b = p.batch;
-  while (hi_b - lo > 1) {
-    const int mid = (lo + hi_b) >> 1;
-    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
-  }
-  const int b = lo;
+  const int b = find_request(p.tile_cu, p.batch, tile, lane);
   const int q_begin = p.cu_q[b];
   const int q_len = p.cu_q[b + 1] - q_begin;
   const int k_len = p.seq_lens[b];
@@ -871,12 +880,7 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillPa
   const int hq = kvh * p.group + (rem - ti * p.group);
   const int tile = p.tile_order ? p.tile_order[ti] : ti;
 
-  int lo = 0, hi_b = p.batch;
-  while (hi_b - lo > 1) {
-    const int mid = (lo + hi_b) >> 1;
-    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
-  }
-  const int b = lo;
+  const int b = find_request(p.tile_cu, p.batch, tile, lane);
   const int q_begin = p.cu_q[b];
   const int q_len = p.cu_q[b + 1] - q_begin;
   const int k_len = p.seq_lens[b];

@@ -28,7 +28,7 @@ VARIANTS = {
 }
 
 
-DMA_VARIANTS = {0: "full", 16: "full, no s_setprio", 32: "full, s_setprio 1 on the softmax instead of the MFMA blocks", 1: "no K/V stream", 4: "no softmax", 2: "no QK^T", 8: "no PV", 6: "PV + stream", 12: "QK^T + stream",
+DMA_VARIANTS = {0: "full", 16: "full, s_setprio 1 on the MFMA blocks", 32: "full, s_setprio 1 on the softmax", 1: "no K/V stream", 4: "no softmax", 2: "no QK^T", 8: "no PV", 6: "PV + stream", 12: "QK^T + stream",
                 10: "softmax + stream", 14: "stream + barrier only", 15: "loop skeleton"}
 
 
@@ -40,6 +40,8 @@ PP_VARIANTS = {11: "softmax only (no MFMA, no LDS reads, no stream)", 5: "MFMA +
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/prefill_ablate.json")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--only", nargs="*", help="label prefixes to run, e.g. 'dma: full' 'tr: full'")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     import bench as _bench
@@ -50,44 +52,36 @@ def main():
     res = {}
     for name, ql, kl, hq, hkv in cases:
         c = prefill_case(ql, kl, hq, hkv, 256, dev)
-        row = {}
-        for bits, label in VARIANTS.items():
-            f = lambda: ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"],  # noqa: E731
-                                         c["tile_cu"], c["B"], c["total_tiles"], 128 ** -0.5, tile_order=c["order"],
-                                         impl=(16 + bits) if bits else 2)
-            us = time_us(f, iters=10, warmup=10)
-            row[label] = dict(us=round(us, 1), frac_if_full=round(c["flops"] / us / 1e6 / MFMA_PEAK_TFLOPS, 3))
-        outs = {}
-        for impl in (2, 4):
-            c["out"].zero_()
-            ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"], c["tile_cu"], c["B"],
-                             c["total_tiles"], 128 ** -0.5, tile_order=c["order"], impl=impl)
-            outs[impl] = c["out"].clone()
-        row["dma == tr (bitwise)"] = bool(torch.equal(outs[2], outs[4]))
-        row["dma vs tr max abs diff"] = float((outs[2].float() - outs[4].float()).abs().max())
-        for bits, label in DMA_VARIANTS.items():
-            f = lambda: ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"],  # noqa: E731
-                                         c["tile_cu"], c["B"], c["total_tiles"], 128 ** -0.5, tile_order=c["order"],
-                                         impl=(64 + bits) if bits else 4)
-            us = time_us(f, iters=10, warmup=10)
-            row["dma: " + label] = dict(us=round(us, 1), frac_if_full=round(c["flops"] / us / 1e6 / MFMA_PEAK_TFLOPS, 3))
         c2 = prefill_case(ql, kl, hq, hkv, 256, dev, q_tile=256)
         for k_ in ("q", "k", "v", "table"):
             c2[k_] = c[k_]
-        c2["out"].zero_()
-        ops.attn_prefill(c2["out"], c2["q"], c2["k"], c2["v"], c2["table"], None, c2["seq"], c2["cu_q"], c2["tile_cu"], c2["B"],
-                         c2["total_tiles"], 128 ** -0.5, tile_order=c2["order"], impl=5)
-        row["pp == tr (bitwise)"] = bool(torch.equal(outs[2], c2["out"]))
-        row["pp vs tr max abs diff"] = float((outs[2].float() - c2["out"].float()).abs().max())
-        for bits, label in PP_VARIANTS.items():
-            f = lambda: ops.attn_prefill(c2["out"], c2["q"], c2["k"], c2["v"], c2["table"], None, c2["seq"], c2["cu_q"],  # noqa: E731
-                                         c2["tile_cu"], c2["B"], c2["total_tiles"], 128 ** -0.5, tile_order=c2["order"],
-                                         impl=(128 + bits) if bits else 5)
-            us = time_us(f, iters=10, warmup=10)
-            row["pp: " + label] = dict(us=round(us, 1), frac_if_full=round(c["flops"] / us / 1e6 / MFMA_PEAK_TFLOPS, 3))
+
+        def launch(cc, impl):
+            ops.attn_prefill(cc["out"], cc["q"], cc["k"], cc["v"], cc["table"], None, cc["seq"], cc["cu_q"], cc["tile_cu"],
+                             cc["B"], cc["total_tiles"], 128 ** -0.5, tile_order=cc["order"], impl=impl)
+
+        row, outs = {}, {}
+        for impl, cc in ((2, c), (4, c), (5, c2)):
+            cc["out"].zero_()
+            launch(cc, impl)
+            outs[impl] = cc["out"].clone()
+        row["dma == tr (bitwise)"] = bool(torch.equal(outs[2], outs[4]))
+        row["pp == tr (bitwise)"] = bool(torch.equal(outs[2], outs[5]))
+        runs = [("tr: " + label, c, (16 + bits) if bits else 2) for bits, label in VARIANTS.items()]
+        runs += [("dma: " + label, c, (64 + bits) if bits else 4) for bits, label in DMA_VARIANTS.items()]
+        runs += [("pp: " + label, c2, (128 + bits) if bits else 5) for bits, label in PP_VARIANTS.items()]
+        if args.only:
+            runs = [r for r in runs if any(r[0].startswith(o) for o in args.only)]
+        best = {}
+        for _ in range(args.rounds):  # variants interleaved, best of the rounds: the first launches after a change of kernel run slower
+            for label, cc, impl in runs:
+                us = time_us(lambda: launch(cc, impl), iters=8, warmup=4)
+                best[label] = min(best.get(label, 1e30), us)
+        for label, us in best.items():
+            row[label] = dict(us=round(us, 1), frac_if_full=round(c["flops"] / us / 1e6 / MFMA_PEAK_TFLOPS, 3))
         res[name] = dict(flops=c["flops"], q_tiles=c["total_tiles"], variants=row)
         print(name, json.dumps(row), flush=True)
-        del c
+        del c, c2
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(res, indent=1))
 
