@@ -70,16 +70,42 @@ __device__ __forceinline__ int64_t slot_offset(int slot, int64_t stride_tok) {
   return (int64_t)((uint64_t)(uint32_t)slot * (uint64_t)(uint32_t)stride_tok);
 }
 
-// request b with tile_cu[b] <= tile < tile_cu[b + 1]: 64 entries per step, one per lane, counted with a ballot -- ONE
-// memory latency for batches up to 64 requests where the bisection paid log2(B) dependent ones (~2 us of a workgroup
-// that computes for ~5 us on the benchmark's prefill chunks)
-__device__ __forceinline__ int find_request(const int* tile_cu, int batch, int tile, int lane) {
+// The request a q tile belongs to and its scalars, in ONE memory latency for batches up to 64 requests (the bisection over
+// tile_cu followed by the four scalar loads paid log2(B) + 1 dependent ones: ~2.5 us of a workgroup that computes for
+// ~5 us on the benchmark's prefill chunks).  Lane i of a 64-request block loads request i's tile_cu, cu_q, cu_q[+1],
+// seq_len and table row together; b = the last request with tile_cu[b] <= tile is counted with a ballot and its values are
+// taken from that lane.
+struct TileRequest {
+  int b, q_begin, q_end, k_len, row, tile_first;
+};
+__device__ __forceinline__ TileRequest find_request(const PrefillParams& p, int tile, int lane) {
+  TileRequest r;
   int base = 0;
   for (;;) {
-    const int idx = base + lane;
-    const int v = idx < batch ? tile_cu[idx] : 0x7fffffff;
-    const int cnt = __popcll(__ballot(v <= tile));
-    if (cnt < 64 || base + 64 >= batch) return __builtin_amdgcn_readfirstlane(base + cnt - 1);
+    const int idx = min(base + lane, p.batch - 1);
+    const int tc = base + lane < p.batch ? p.tile_cu[idx] : 0x7fffffff;
+    const int cq0 = p.cu_q[idx], cq1 = p.cu_q[idx + 1], kl = p.seq_lens[idx];
+    const int rr = p.req_rows ? p.req_rows[idx] : idx;
+    const int cnt = __popcll(__ballot(tc <= tile));
+    if (cnt > 0 && (cnt < 64 || base + 64 >= p.batch)) {
+      const int l = cnt - 1;
+      r.b = base + l;
+      r.tile_first = __builtin_amdgcn_readlane(tc, l);
+      r.q_begin = __builtin_amdgcn_readlane(cq0, l);
+      r.q_end = __builtin_amdgcn_readlane(cq1, l);
+      r.k_len = __builtin_amdgcn_readlane(kl, l);
+      r.row = __builtin_amdgcn_readlane(rr, l);
+      return r;
+    }
+    if (cnt == 0) {  // the last request of the previous block (more than 64 requests only)
+      r.b = base - 1;
+      r.tile_first = p.tile_cu[r.b];
+      r.q_begin = p.cu_q[r.b];
+      r.q_end = p.cu_q[r.b + 1];
+      r.k_len = p.seq_lens[r.b];
+      r.row = p.req_rows ? p.req_rows[r.b] : r.b;
+      return r;
+    }
     base += 64;
   }
 }
@@ -593,12 +619,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const PrefillP
   const int hq = kvh * p.group + (rem - ti * p.group);
   const int tile = p.tile_order ? p.tile_order[ti] : ti;
 
-  const int b = find_request(p.tile_cu, p.batch, tile, lane);
-  const int q_begin = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_begin;
-  const int k_len = p.seq_lens[b];
-  const int q0 = (tile - p.tile_cu[b]) * kQTile;
-  const int row = p.req_rows ? p.req_rows[b] : b;
+  const TileRequest rq = find_request(p, tile, lane);
+  const int q_begin = rq.q_begin;
+  const int q_len = rq.q_end - q_begin;
+  const int k_len = rq.k_len;
+  const int q0 = (tile - rq.tile_first) * kQTile;
+  const int row = rq.row;
   const int* pt = p.page_table + (int64_t)row * p.pt_stride;
   const int diag = k_len - q_len;
   const int kend = min(k_len, diag + min(q0 + kQTile, q_len));
@@ -880,12 +906,12 @@ __global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillPa
   const int hq = kvh * p.group + (rem - ti * p.group);
   const int tile = p.tile_order ? p.tile_order[ti] : ti;
 
-  const int b = find_request(p.tile_cu, p.batch, tile, lane);
-  const int q_begin = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_begin;
-  const int k_len = p.seq_lens[b];
-  const int q0 = (tile - p.tile_cu[b]) * kPPRows;
-  const int row = p.req_rows ? p.req_rows[b] : b;
+  const TileRequest rq = find_request(p, tile, lane);
+  const int q_begin = rq.q_begin;
+  const int q_len = rq.q_end - q_begin;
+  const int k_len = rq.k_len;
+  const int q0 = (tile - rq.tile_first) * kPPRows;
+  const int row = rq.row;
   const int* pt = p.page_table + (int64_t)row * p.pt_stride;
   const int diag = k_len - q_len;
   const int kend = min(k_len, diag + min(q0 + kPPRows, q_len));
