@@ -284,6 +284,14 @@ int msgl_sample_from_logits(int32_t* out, const void* logits, const float* tempe
  * ---------------------------------------------------------------------- */
 int msgl_skinny_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
                         int64_t ldw, int64_t ldo, int dtype, int slices, int row_tiles, void* stream);
+/* The gated-MLP pair at decode-sized M in one launch -- gate_up_proj then act_fn (P/models/utils.py:45-51, P/layers/
+ * activation.py:9-12): w [N, K] is the gate_up weight with its rows interleaved in blocks of 32 (rows 64 j .. + 31 gate,
+ * + 32 .. + 63 up: msgl_silu_and_mul_interleaved's layout), out[M, N/2] = silu(x . gate^T) * (x . up^T) with gate and up
+ * rounded to the 16-bit type before the activation: the same bits as msgl_skinny_gemm_nt followed by
+ * msgl_silu_and_mul_interleaved.  N % 64 == 0, ldo >= N/2; row_tiles 2 or 4 (a wave holds gate and up tiles) or 1 with an
+ * even `slices` (half of the waves stream the gate tile, half the up tile, slices / 2 k-slices each). */
+int msgl_skinny_gemm_silu_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
+                             int64_t ldw, int64_t ldo, int dtype, int slices, int row_tiles, void* stream);
 
 /* Same product for mid-size decode batches (1 <= M <= 256; meant for 32 < M): the 8 waves of a workgroup
  * stream different weight rows over the same k range and share the activation tile through LDS.

@@ -68,7 +68,7 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r["skinny_used"] = True
                     r["kernel"] = ("msgl::%s[grid %d, whole tiles %d, k-slices %d]"
                                    % ((("m256_gemm_kernel", "g3_gemm_kernel")[mr["plan"][3]],) + tuple(mr["plan"][:3])))
-            if flags.get("silu_interleaved") and ops.m256_supported(bs, r["N"], r["K"]):
+            if flags.get("silu_interleaved") and (ops.m256_supported(bs, r["N"], r["K"]) or bs <= ops.SKINNY_MAX_M):
                 fr = ops.fused_silu_tune(x, ws)  # projection + activation as one launch vs the two just planned
                 r.update(silu_unfused_us=fr["unfused_us"], silu_fused_us=fr["fused_us"], silu_fused_plan=fr["plan"],
                          silu_fused_used=fr["used"], silu_fused_all=fr.get("all"))
@@ -76,7 +76,10 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r.setdefault("library_best_us", r["best_us"])
                     r["best_us"] = fr["fused_us"]  # projection AND activation
                     r["skinny_used"] = True
-                    r["kernel"] = "msgl::g3_gemm_kernel<silu>[grid %d, whole tiles %d, k-slices %d]" % tuple(fr["plan"])
+                    if fr.get("kind") == "skinny":
+                        r["kernel"] = "msgl::skinny_gemm_kernel<silu>[slices %d, row tiles %d]" % tuple(fr["plan"])
+                    else:
+                        r["kernel"] = "msgl::g3_gemm_kernel<silu>[grid %d, whole tiles %d, k-slices %d]" % tuple(fr["plan"])
             ops.register_candidates(name, x, ws[0], r)
             report.append(r)
             if log is not None:

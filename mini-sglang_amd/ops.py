@@ -510,6 +510,44 @@ def skinny_linear(x: torch.Tensor, w: torch.Tensor, slices: int, out: Optional[t
     return out
 
 
+_SKINNY_SILU_PLAN: dict = {}  # (device, M, N, K, ldx, ldw, dtype code), w = interleaved gate_up -> (k-slices, row tiles) of the fused launch
+
+
+def skinny_linear_silu(x: torch.Tensor, w: torch.Tensor, slices: int, out: Optional[torch.Tensor] = None,
+                       row_tiles: int = 2) -> torch.Tensor:
+    """out[M, N/2] = silu(x @ gate^T) * (x @ up^T) for a gate_up weight in interleave_gate_up order, one launch of
+    msgl_skinny_gemm_silu_nt (M <= 64): the same bits as skinny_linear + silu_and_mul_interleaved."""
+    _need_cuda(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.dtype == w.dtype
+    assert x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N // 2), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, N // 2) and out.stride(1) == 1 and out.dtype == x.dtype
+    _no_pending_slabs(x.device)
+    check(
+        lib().msgl_skinny_gemm_silu_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                       out.stride(0), _dt(x), slices, row_tiles, _stream()),
+        "skinny_gemm_silu_nt",
+    )
+    return out
+
+
+def skinny_silu_candidates(M: int, N: int, K: int):
+    """(k-slices, row tiles per wave) settings of the fused gate_up + SiLU.mul launch (row tiles come in gate / up pairs)."""
+    if N % 64:
+        return []
+    mt = 1 if M <= 16 else 2 if M <= 32 else 4
+    out = []
+    cap1 = 16 if mt <= 2 else 8
+    out += [(sl, 1) for sl in (2, 4, 8, 16) if sl <= cap1 and sl // 2 <= K // 64]  # gate / up on the two halves of the waves
+    for nt in (2, 4):
+        cap = min(16 if mt * nt <= 2 else 8 if mt * nt <= 8 else 4, K // 64)
+        out += [(sl, nt) for sl in (1, 2, 4, 8, 16) if sl <= cap]
+    return out
+
+
 def skinny_candidates(M: int, N: int, K: int):
     """(k-slices, row tiles per wave) settings the kernel accepts for this shape (csrc/gemm_skinny.hip)."""
     mt = 1 if M <= 16 else 2 if M <= 32 else 4
@@ -749,6 +787,21 @@ def fused_silu_tune(x: torch.Tensor, weights, iters: int = 8) -> dict:
     res = dict(M=M, N=N, K=K, unfused_us=None, fused_us=None, plan=None, used=False)
     key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
     _FUSED_SILU_PLAN.pop(key, None)
+    _SKINNY_SILU_PLAN.pop(key, None)
+    if M <= SKINNY_MAX_M and skinny_supported(M, N, K) and N % 64 == 0 and os.environ.get("MSGL_DISABLE_SKINNY_SILU") != "1":
+        # decode-sized batch: the weight-streaming kernel with the activation in its epilogue against whatever `linear`
+        # is planned to do for the shape + the activation kernel
+        half = torch.empty((M, N // 2), dtype=x.dtype, device=x.device)
+        res["unfused_us"] = _time_launches_us(lambda w: silu_and_mul_interleaved(linear(x, w), half), weights, iters, 3)
+        ranked = sorted((_time_launches_us(lambda w: skinny_linear_silu(x, w, sl, half, nt), weights, iters, 1), (sl, nt))
+                        for sl, nt in skinny_silu_candidates(M, N, K))
+        best = min((_time_launches_us(lambda w: skinny_linear_silu(x, w, p[0], half, p[1]), weights, iters, 3), p)
+                   for _, p in ranked[:4])
+        res.update(fused_us=best[0], plan=best[1], kind="skinny")
+        if best[0] < res["unfused_us"]:  # one launch less in front of the same consumer: no margin asked
+            _SKINNY_SILU_PLAN[key] = best[1]
+            res["used"] = True
+        return res
     if not (m256_supported(M, N, K) and (N // 2) % 64 == 0) or os.environ.get("MSGL_DISABLE_G3") == "1":
         return res
     cus = int(lib().msgl_device_cu_count())
@@ -772,6 +825,10 @@ def linear_silu(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
     gate_up_proj then act_fn): one fused launch where fused_silu_tune planned it, else linear + the activation kernel."""
     M, K = x.shape
     N = w.shape[0]
+    if M <= SKINNY_MAX_M and _SKINNY_SILU_PLAN:
+        plan = _SKINNY_SILU_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return skinny_linear_silu(x, w, plan[0], out, plan[1])
     if M >= M256_MIN_M and _FUSED_SILU_PLAN:
         plan = _FUSED_SILU_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
@@ -905,6 +962,8 @@ def register_candidates(name: str, x: torch.Tensor, w: torch.Tensor, report: dic
 
 
 def current_candidate(key) -> str:
+    if key in _SKINNY_SILU_PLAN:
+        return f"skinny fused SiLU.mul {_SKINNY_SILU_PLAN[key]}"
     if key in _FUSED_SILU_PLAN:
         return f"g3 fused SiLU.mul {_FUSED_SILU_PLAN[key]}"
     if key in _M256_PLAN:
@@ -958,6 +1017,7 @@ def reset_gemm_plans() -> None:
     _WSTREAM_PLAN.clear()
     _M256_PLAN.clear()
     _FUSED_SILU_PLAN.clear()
+    _SKINNY_SILU_PLAN.clear()
     _CANDIDATES.clear()
     _PENDING_SLABS.clear()
     _PENDING_ALLREDUCE.clear()

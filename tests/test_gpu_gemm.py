@@ -352,6 +352,42 @@ def test_g3_fused_silu_equals_projection_then_activation(ops, dev, dtype, M, int
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,inter,K", [(1, 17408, 5120), (3, 3072, 1024), (16, 512, 640), (17, 1024, 512), (32, 128, 64), (33, 2048, 1024),
+                                      (64, 4352, 5120)])
+def test_skinny_fused_silu_equals_projection_then_activation(ops, dev, dtype, M, inter, K):
+    """Decode-sized batches: gate_up_proj + silu_and_mul (P/models/utils.py:45-51, P/layers/activation.py:9-12) as ONE launch
+    of the weight-streaming kernel on the interleaved weight: for every (k-slices, row tiles) setting bit-identical to the
+    same projection rounded to 16 bits followed by the activation kernel; within the activation's bound of the fp32 oracle;
+    rows past M and columns past N/2 untouched; linear_silu dispatches on the plan."""
+    from oracle import ref_ops
+
+    g = torch.Generator(device=dev).manual_seed(M + inter + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(dtype)
+    w = (torch.randn((2 * inter, K), generator=g, device=dev) * 0.05).to(dtype)
+    wi = ops.interleave_gate_up(w)
+    want = ref_ops.silu_and_mul_ref(_ref(x, w).to(dtype).cpu()).float().to(dev)
+    cands = ops.skinny_silu_candidates(M, 2 * inter, K)
+    assert cands and {nt for _, nt in cands} == {1, 2, 4}
+    for sl, nt in cands:
+        fused = torch.full((M + 1, inter + 8), float("nan"), dtype=dtype, device=dev)
+        ops.skinny_linear_silu(x, wi, sl, fused[:M, :inter], nt)
+        assert bool(fused[M:].isnan().all()) and bool(fused[:, inter:].isnan().all())
+        # row tiles 1: the waves split between the gate and the up tile, sl / 2 k-slices each
+        unfused = ops.silu_and_mul_interleaved(ops.skinny_linear(x, wi, sl // 2 if nt == 1 else sl, None, nt))
+        assert torch.equal(fused[:M, :inter], unfused), (sl, nt)
+        err = (fused[:M, :inter].float() - want).abs()
+        assert err.max().item() <= 2 ** -6 * max(want.abs().max().item(), 1e-3), (sl, nt, err.max().item())
+    key = (dev.index or 0, M, 2 * inter, K, x.stride(0), wi.stride(0), ops._dt(x))
+    try:
+        ops._SKINNY_SILU_PLAN[key] = cands[-1]
+        assert torch.equal(ops.linear_silu(x, wi), ops.skinny_linear_silu(x, wi, *cands[-1][:1], None, cands[-1][1]))
+    finally:
+        ops._SKINNY_SILU_PLAN.clear()
+    with pytest.raises(RuntimeError):
+        ops.skinny_linear_silu(x, wi, 1, None, 1)  # one tile per wave: gate and up need a wave each
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,split", [(256, 5120, 5120, 6), (256, 5120, 17408, 13), (130, 1024, 3072, 4), (256, 640, 640, 10)])
 @pytest.mark.parametrize("impl", [0, 1])
 def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, split, impl):
