@@ -156,12 +156,12 @@ def measure_prefill_attention(device, hq: int, hkv: int, budget: int = 16384):
     from mini_sglang_amd import ops
 
     lens = prefill_chunk_lens(budget, bench_contexts(256))
-    c = prefill_case(lens, lens, hq, hkv, 256, device)
+    c = prefill_case(lens, lens, hq, hkv, 256, device, q_tile=ops.prefill_q_tile())
     us = time_us(lambda: ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"],
                                           c["tile_cu"], c["B"], c["total_tiles"], 128 ** -0.5,
-                                          tile_order=c["order"]), iters=10, warmup=2)
+                                          tile_order=c["order"]), iters=20, warmup=10)
     tf = c["flops"] / us / 1e6
-    return {"bound": "mfma", "kernel": "attn_prefill_tr_kernel, one layer, one chunk", "achieved": tf,
+    return {"bound": "mfma", "kernel": "attn_prefill_dma_kernel (the default prefill kernel), one layer, one chunk", "achieved": tf,
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "us_per_launch": us,
             "flops": c["flops"], "chunk_tokens": c["T"], "requests": c["B"]}
 

@@ -64,7 +64,11 @@ constexpr float kNegBig = -3.0e38f;
 
 // plan buffer layout (int32 words):
 //   hdr[4] | item_start[max_bs] | n_chunks[max_bs] | tile_start[max_bs] | slot_first[capacity + 1] |
-//   items[4 * capacity] = (request, first tile, end tile, slot) | arrivals[max_bs * kTicketHeads]
+//   items[4 * capacity] = (request, first tile, end tile, slot) |
+//   items2[4 * capacity] = (seq_len, pieces of the request, its first piece, 0) | arrivals[max_bs * kTicketHeads]
+// items2 repeats per piece what the kernels otherwise fetch by request AFTER the piece record arrived: with it a piece's
+// scalars are two independent loads at an address known from the piece number alone (and are prefetched for piece i + 1
+// while piece i streams).
 // arrivals[b][kv head]: how many pieces of request b have published their partial sums in the running launch (matrix-core
 // kernel under select code 72: the piece that arrives last combines them).  Zeroed by the plan kernel, left at zero by
 // every launch.
@@ -76,8 +80,11 @@ __host__ __device__ inline int64_t plan_off_slot_first(int max_bs) { return kPla
 __host__ __device__ inline int64_t plan_off_items(int max_bs, int capacity) {
   return ((kPlanHdr + 3ll * max_bs + capacity + 1 + 3) / 4) * 4;  // int4-aligned
 }
-__host__ __device__ inline int64_t plan_off_arrivals(int max_bs, int capacity) {
+__host__ __device__ inline int64_t plan_off_items2(int max_bs, int capacity) {
   return plan_off_items(max_bs, capacity) + 4ll * capacity;
+}
+__host__ __device__ inline int64_t plan_off_arrivals(int max_bs, int capacity) {
+  return plan_off_items2(max_bs, capacity) + 4ll * capacity;
 }
 
 // ------------------------------------------------------------------------------
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan
   int* tile_start = plan + plan_off_tile_start(max_bs);
   int* slot_first = plan + plan_off_slot_first(max_bs);
   int* items = plan + plan_off_items(max_bs, capacity);
+  int* items2 = plan + plan_off_items2(max_bs, capacity);
 
   // thread t owns a contiguous request segment
   const int per = (batch + 255) / 256;
@@ -162,6 +170,11 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int* __restrict__ plan
       it[1] = g0 - ts;
       it[2] = g1 - ts;
       it[3] = k;
+      int* i2 = items2 + 4 * (int64_t)(run + j);
+      i2[0] = seq_lens[b];
+      i2[1] = n;
+      i2[2] = run;
+      i2[3] = 0;
       if (g0 == k * q) slot_first[k] = run + j;  // every slot starts with exactly one such piece
     }
     run += n;
@@ -599,7 +612,7 @@ __device__ __forceinline__ int vimg_off(int tok, int byte_in_row) {
 // kLoadsOnly (diagnosis, variant 92): the same requests and waits with the products left out -- what the request
 // pattern alone costs
 template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false, bool kTrace = false,
-          bool kCombine = false>
+          bool kCombine = false, bool kPrefetch = true>
 __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kernel(const DecodeParams p) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * 4096];
@@ -636,17 +649,36 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
 
   const __amdgpu_buffer_rsrc_t part_rsrc = make_rsrc(p.part_o);  // the fp32 partial sums (offsets < 2^31: checked at launch)
   mark();  // 1: slot known
+  // A piece's scalars come from its two plan records (address known from the piece number); the records of piece i + 1, its
+  // table row and the pool slots of its first tiles are fetched while piece i's first tiles are in flight, so a wave's
+  // second and later pieces start requesting K/V without a metadata chain in front (tools/decode_trace.py measured
+  // ~10 k clocks of it per further piece with the loads queued behind the stream).
+  const int4* items2 = reinterpret_cast<const int4*>(p.plan + plan_off_items2(p.max_bs, p.capacity));
+  if (item_begin >= item_end) return;  // (every slot of a plan starts with a piece; this keeps a corrupt plan from indexing with garbage)
+  int4 it = items[item_begin], it2 = items2[item_begin];
+  int b = sgpr(it.x);
+  int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
+  int pre_sl[kStages];  // pool slots of the first kStages tiles of the piece about to start (valid from the second piece on)
+#pragma unroll
+  for (int st = 0; st < kStages; ++st) pre_sl[st] = 0;
   for (int item = item_begin; item < item_end; ++item) {
-    const int4 it = items[item];
-    const int b = sgpr(it.x);
-    const int S = sgpr(p.seq_lens[b]);
+    if constexpr (!kPrefetch) {  // select code 94 (diagnosis): the dependent chain of the earlier form, for same-process A/B
+      it = items[item];
+      b = sgpr(it.x);
+      it2.x = p.seq_lens[b];
+      row = p.req_rows ? sgpr(p.req_rows[b]) : b;
+      it2.y = n_chunks[b];
+      it2.z = p.plan[plan_off_item_start() + b];
+    }
+    const int S = sgpr(it2.x);
     const int t0 = sgpr(it.y) * 16;
     const int t1 = min(S, sgpr(it.z) * 16);
-    const int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
-    const int nch = sgpr(n_chunks[b]);  // read here, with the rest of the metadata, not on the way out
-    const int first_item = sgpr(p.plan[plan_off_item_start() + b]);
+    const int nch = sgpr(it2.y);
+    const int first_item = sgpr(it2.z);
     const bool single = nch == 1;
     const CInt* cpt = (const CInt*)(p.page_table + (int64_t)row * p.pt_stride);
+    const int nxt = min(item + 1, item_end - 1);  // the last piece re-reads its own records
+    const int4 nit = items[nxt], nit2 = items2[nxt];
     const int hq0 = h * G;
     const int kvh = hq0 / p.group;
     mark();  // 2 + 4 i: piece i metadata known
@@ -734,12 +766,23 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
     // products), consume it.  Pool slots come through the scalar cache one tile ahead of their use.
     Tile ring[kStages];
     const int lt = ntiles - 1;
+    const bool have_pre = kPrefetch && item > item_begin;
 #pragma unroll
     for (int st = 0; st < kStages - 1; ++st) {
-      load_tile(cpt[t0 + min(st, lt) * 16], ring[st], st);
+      load_tile(have_pre ? pre_sl[st] : cpt[t0 + min(st, lt) * 16], ring[st], st);
       MSGL_PIN_MEM();  // oldest tile first: the scheduler is otherwise free to request them in any order
     }
-    int sn = cpt[t0 + min(kStages - 1, lt) * 16];  // slot of the next tile to request
+    int sn = have_pre ? pre_sl[kStages - 1] : cpt[t0 + min(kStages - 1, lt) * 16];  // slot of the next tile to request
+    // the next piece's row and first slots (its records were requested above; this wait overlaps the first tiles' flight)
+    const int nb = sgpr(nit.x);
+    const int nrow = p.req_rows ? sgpr(p.req_rows[nb]) : nb;
+    {
+      const CInt* ncpt = (const CInt*)(p.page_table + (int64_t)nrow * p.pt_stride);
+      const int nt0 = sgpr(nit.y) * 16;
+      const int nlt = ((min(sgpr(nit2.x), sgpr(nit.z) * 16) - nt0 + 15) >> 4) - 1;
+#pragma unroll
+      for (int st = 0; st < kStages; ++st) pre_sl[st] = ncpt[nt0 + min(st, nlt) * 16];
+    }
     for (int tix = 0; tix < ntiles; tix += kStages) {
 #pragma unroll
       for (int st = 0; st < kStages; ++st) {
@@ -849,6 +892,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
       }
     }
     mark();  // 5 + 4 i: results stored (issued)
+    it = nit;
+    it2 = nit2;
+    b = nb;
+    row = nrow;
   }
   if constexpr (kTrace) {
     if (p.trace && lane == 0) {
@@ -1041,6 +1088,9 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
       if (combine) MSGL_MFMA_LAUNCH(2, 8, 2, true, false, true);
       else MSGL_MFMA_LAUNCH(2, 8, 2, true, false, false);
       break;
+    case 94:  // variant 22 with each piece's scalars fetched by the dependent chain request -> length, row, slots (A/B)
+      MSGL_MFMA_LAUNCH(2, 8, 2, false, false, false, false);
+      break;
     case 93:  // variant 22 with clock stamps per wave (msgl_attn_decode_trace)
       if (combine) MSGL_MFMA_LAUNCH(2, 8, 2, false, true, true);
       else MSGL_MFMA_LAUNCH(2, 8, 2, false, true, false);
@@ -1092,7 +1142,7 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 72 || impl == 92 || impl == 93,
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 72 || impl == 92 || impl == 93 || impl == 94,
                "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
                "w waves per SIMD and s ring stages)", impl);
   g_decode_impl = impl;

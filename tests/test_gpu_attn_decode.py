@@ -151,7 +151,9 @@ def read_plan(plan, max_bs, capacity, batch):
     o_start, o_chunks, o_tiles, o_first = 4, 4 + max_bs, 4 + 2 * max_bs, 4 + 3 * max_bs
     o_items = (4 + 3 * max_bs + capacity + 1 + 3) // 4 * 4
     items = [tuple(plan[o_items + 4 * i: o_items + 4 * i + 4]) for i in range(n_items)]
-    return dict(n_items=n_items, slot_tokens=slot_tokens, n_slots=n_slots, items=items,
+    o_items2 = o_items + 4 * capacity  # per piece: (seq_len, pieces of the request, its first piece, 0)
+    items2 = [tuple(plan[o_items2 + 4 * i: o_items2 + 4 * i + 4]) for i in range(n_items)]
+    return dict(n_items=n_items, slot_tokens=slot_tokens, n_slots=n_slots, items=items, items2=items2,
                 item_start=plan[o_start: o_start + batch], n_chunks=plan[o_chunks: o_chunks + batch],
                 tile_start=plan[o_tiles: o_tiles + batch], slot_first=plan[o_first: o_first + n_slots + 1])
 
@@ -171,6 +173,8 @@ def check_plan(pl, lens):
         load[k] += t1 - t0
         assert pl["slot_first"][k] <= i < pl["slot_first"][k + 1]
     assert cover == nts
+    for (b, _t0, _t1, _k), (seq, nch, first, _z) in zip(pl["items"], pl["items2"]):  # the per-piece copy of the request's scalars
+        assert (seq, nch, first) == (lens[b], pl["n_chunks"][b], pl["item_start"][b])
     assert all(x == q for x in load[:-1]) and 0 < load[-1] <= q
     assert pl["slot_first"][-1] == pl["n_items"]
     for b, n in enumerate(nts):

@@ -57,7 +57,7 @@ for cfg in "qwen3-14b 2" "qwen3-14b 4" "qwen3-14b 8" "qwen3-32b 4"; do set -- $c
 bash tools/trace_small_batch.sh ${TAG} 1 > gpurun_out/${TAG}_b1_trace.log 2>&1; head -3 gpurun_out/${TAG}_b1_kernel_breakdown.txt
 # same-box A/B of the decode attention kernels, per-wave clock stamps of the default one, MFMA counters of prefill attention
 cd $R
-timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,0.6b,14b_b32 --impls 1,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
+timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,0.6b,14b_b32 --impls 1,94,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
 head -8 gpurun_out/${TAG}_decode_ab.txt
 timeout 200 python tools/decode_trace.py --out gpurun_out/${TAG}_decode_trace.json > /dev/null 2>&1
 cd /tmp
