@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -88,26 +89,32 @@ struct Problem {
 // member functions, so a layout difference between the two versions cannot overrun it.
 struct GemmBox {
   alignas(64) unsigned char raw[2048];
+  bool live = false;  // a Gemm has been constructed in `raw`
   hipblaslt_ext::Gemm* get() { return reinterpret_cast<hipblaslt_ext::Gemm*>(raw); }
+  ~GemmBox() {
+    if (live) get()->~Gemm();  // the library's own exported destructor, like the constructor
+  }
 };
 
 struct Plan {
-  Problem* prob = nullptr;  // owned for process lifetime
+  std::shared_ptr<Problem> prob;  // shared by the candidates of one search; freed with the last plan that refers to it
   hipblasLtMatmulAlgo_t algo;
   size_t workspace = 0;
   bool tuned = false;
   int algo_index = -1;
   int split_k = 0;          // 0: the solution's own setting (plain hipblasLtMatmul); > 0: ext Gemm + GemmTuning
-  GemmBox* box = nullptr;   // owned for process lifetime (split_k > 0 only)
+  std::shared_ptr<GemmBox> box;   // split_k > 0 only; shared like `prob`
 };
 
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;  // per device
-std::map<Key, Plan> g_plans;
+// The tables live on the heap and are never destroyed: at process exit the library the plans' objects call into may
+// already be gone.  msgl_gemm_reset_plans frees the objects of dropped plans explicitly.
+std::map<Key, Plan>& g_plans = *new std::map<Key, Plan>();
 // the best few candidates of the last search per shape, fastest first (msgl_gemm_finalists / msgl_gemm_select_finalist):
 // back-to-back timing separates the top solutions by ~1 %, inside a captured decode step they differ by up to 9 %, so the
 // host re-ranks them in place (engine.Engine.refine_plans_in_graph)
-std::map<Key, std::vector<std::pair<float, Plan>>> g_finalists;
+std::map<Key, std::vector<std::pair<float, Plan>>>& g_finalists = *new std::map<Key, std::vector<std::pair<float, Plan>>>();
 // Untuned (heuristic) plans are created on first use of a shape; prefill M = total extend tokens takes almost any
 // value, so a long-running server would grow the map without bound.  Tuned plans (decode shapes, a few dozen) are
 // kept; untuned ones are dropped oldest-first beyond this many.
@@ -115,10 +122,8 @@ constexpr size_t kMaxUntunedPlans = 256;
 std::deque<Key> g_untuned_order;
 
 void release_plan(Plan& pl) {
-  delete pl.prob;
-  delete pl.box;
-  pl.prob = nullptr;
-  pl.box = nullptr;
+  pl.prob.reset();
+  pl.box.reset();
 }
 
 void remember_untuned(const Key& key) {
@@ -236,8 +241,8 @@ int msgl_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, i
   auto it = g_plans.find(key);
   if (it == g_plans.end()) {
     Plan pl;
-    pl.prob = new Problem();
-    if ((rc = make_problem(pl.prob, M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
+    pl.prob = std::make_shared<Problem>();
+    if ((rc = make_problem(pl.prob.get(), M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
     if ((rc = heuristic_plan(h, &pl, ws_bytes)) != MSGL_OK) return rc;
     it = g_plans.emplace(key, pl).first;
     remember_untuned(key);
@@ -262,8 +267,8 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   const size_t ws_bytes = workspace ? (size_t)std::max<int64_t>(workspace_bytes, 0) : 0;
 
   Plan base;
-  base.prob = new Problem();
-  if ((rc = make_problem(base.prob, M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
+  base.prob = std::make_shared<Problem>();
+  if ((rc = make_problem(base.prob.get(), M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
   if ((rc = heuristic_plan(h, &base, ws_bytes)) != MSGL_OK) return rc;
 
   const hipDataType t = dtype == MSGL_BF16 ? HIP_R_16BF : HIP_R_16F;
@@ -313,9 +318,10 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   // split-K variants of every supported solution (the few-tile shapes N <= 8192 of a decode step leave
   // most CUs idle otherwise).
   if (split_search) {
-    GemmBox* box = new GemmBox();
+    auto box = std::make_shared<GemmBox>();
     new (box->raw) hipblaslt_ext::Gemm(h, base.prob->desc, &alpha, w_list[0], base.prob->a, x, base.prob->b, &beta,
                                        out, base.prob->d, out, base.prob->d);
+    box->live = true;
     const size_t n_plain = cands.size();
     static const int kSplits[] = {2, 3, 4, 6, 8, 12, 16};
     for (size_t i = 0; i < n_plain; ++i) {
@@ -417,7 +423,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
   Plan chosen = cands[best_i];
   chosen.tuned = true;
   const Key key{dev, M, N, K, ldx, ldw, ldo, dtype};
-  g_plans[key] = chosen;  // base.prob stays alive (shared by the map entry)
+  g_plans[key] = chosen;
   {
     std::vector<std::pair<float, Plan>> fl;
     for (int r = 0; r < finals; ++r)
@@ -442,9 +448,7 @@ int msgl_gemm_tune(void* out, const void* x, const void* const* w_list, int n_w,
 // state; an engine that asks for gemm_tune = "off" must not inherit what an earlier engine searched.
 int msgl_gemm_reset_plans(void) {
   std::lock_guard<std::mutex> lock(g_mu);
-  // (Problem objects of tuned plans are shared between the candidates of one search and stay allocated)
-  for (auto& kv : g_plans)
-    if (!kv.second.tuned) release_plan(kv.second);
+  // the problem descriptors / split-K objects are reference-counted: dropped with the last plan or finalist holding them
   g_plans.clear();
   g_finalists.clear();
   g_untuned_order.clear();

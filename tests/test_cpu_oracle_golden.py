@@ -253,8 +253,8 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.msgl_attn_decode(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 2, 4, 16, 8, 3, 128, 1024, 384, 128,
                               1024, 0.1, 1, 0, None) == -1  # 8 q heads / 3 kv heads
     assert L.msgl_attn_decode_plan_words(8, 4) == -1
-    # hdr 4 | item_start 8 | n_chunks 8 | tile_start 8 | slot_first 65 -> 93, int4-aligned 96 | items 4 * 64
-    assert L.msgl_attn_decode_plan_words(8, 64) == 96 + 256 + 8 * 64  # + arrival counters: 8 requests x 64 kv heads
+    # hdr 4 | item_start 8 | n_chunks 8 | tile_start 8 | slot_first 65 -> 93, int4-aligned 96 | items 4 * 64 | items2 4 * 64
+    assert L.msgl_attn_decode_plan_words(8, 64) == 96 + 256 + 256 + 8 * 64  # + arrival counters: 8 requests x 64 kv heads
     assert L.msgl_attn_decode_workspace_bytes(64, 40, 128) == 64 * 40 * 130 * 4
     assert L.msgl_fast_compare_key(None, 3, None, 3, 4) == -1
     with pytest.raises(RuntimeError):

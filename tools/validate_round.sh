@@ -57,7 +57,7 @@ for cfg in "qwen3-14b 2" "qwen3-14b 4" "qwen3-14b 8" "qwen3-32b 4"; do set -- $c
 bash tools/trace_small_batch.sh ${TAG} 1 > gpurun_out/${TAG}_b1_trace.log 2>&1; head -3 gpurun_out/${TAG}_b1_kernel_breakdown.txt
 # same-box A/B of the decode attention kernels, per-wave clock stamps of the default one, MFMA counters of prefill attention
 cd $R
-timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,0.6b,14b_b32 --impls 1,94,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
+timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,70b_tp8,0.6b,14b_b32 --impls 1,94,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
 head -8 gpurun_out/${TAG}_decode_ab.txt
 timeout 200 python tools/decode_trace.py --out gpurun_out/${TAG}_decode_trace.json > /dev/null 2>&1
 cd /tmp
@@ -66,3 +66,19 @@ DB=$(find $R/gpurun_out/${TAG}_pmc_mfma -name "*results.db" | head -1)
 timeout 120 python $R/tools/rocpd_summary.py $DB --top 12 > $R/gpurun_out/${TAG}_pmc_mfma_prefill_attention.txt 2>&1
 grep -A6 "kernel,counter" $R/gpurun_out/${TAG}_pmc_mfma_prefill_attention.txt | cut -c1-160
 find $R/gpurun_out/${TAG}_pmc_mfma -name "*.db" -delete
+# prefill attention: kernel generations timed interleaved + the default kernel's ablations, wave-level counters, segment stamps of
+# the counter-phase kernel; fused gate_up + SiLU.mul of the weight-streaming kernel against projection + activation
+cd $R
+timeout 200 python tools/prefill_ablate.py --rounds 3 --only "tr: full" "dma: " "pp: full" --out gpurun_out/${TAG}_prefill_variants.json > gpurun_out/${TAG}_prefill_variants.log 2>&1
+python - <<PY
+import json
+try:
+    r = json.load(open("gpurun_out/${TAG}_prefill_variants.json"))
+    for n, c in r.items():
+        print(n, {k: v["frac_if_full"] for k, v in c["variants"].items() if isinstance(v, dict) and k in ("tr: full", "dma: full", "pp: full")})
+except Exception as e:
+    print("prefill variants unreadable:", e)
+PY
+timeout 300 bash tools/pmc_prefill.sh ${TAG} 2 4 5 > gpurun_out/${TAG}_pmc_prefill.log 2>&1; grep -c "SQ_" gpurun_out/${TAG}_pmc_prefill.txt
+timeout 100 python tools/prefill_trace.py --out gpurun_out/${TAG}_prefill_trace_pp.json 2>&1 | grep group | cut -c1-300
+timeout 100 python tools/skinny_silu_bench.py --out gpurun_out/${TAG}_skinny_silu_bench.json 2>&1 | tail -3 | cut -c1-200
