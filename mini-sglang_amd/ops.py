@@ -792,7 +792,8 @@ def fused_silu_tune(x: torch.Tensor, weights, iters: int = 8) -> dict:
         # decode-sized batch: the weight-streaming kernel with the activation in its epilogue against whatever `linear`
         # is planned to do for the shape + the activation kernel
         half = torch.empty((M, N // 2), dtype=x.dtype, device=x.device)
-        res["unfused_us"] = _time_launches_us(lambda w: silu_and_mul_interleaved(linear(x, w), half), weights, iters, 3)
+        full = torch.empty((M, N), dtype=x.dtype, device=x.device)  # (no allocation inside the timed pair: it is not there under replay)
+        res["unfused_us"] = _time_launches_us(lambda w: silu_and_mul_interleaved(linear(x, w, full), half), weights, iters, 3)
         ranked = sorted((_time_launches_us(lambda w: skinny_linear_silu(x, w, sl, half, nt), weights, iters, 1), (sl, nt))
                         for sl, nt in skinny_silu_candidates(M, N, K))
         best = min((_time_launches_us(lambda w: skinny_linear_silu(x, w, p[0], half, p[1]), weights, iters, 3), p)
