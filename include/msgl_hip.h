@@ -300,6 +300,11 @@ int msgl_skinny_gemm_silu_nt(void* out, const void* x, const void* w, int M, int
  * msgl_wstream_gemm_workspace_bytes(M, N, k_splits) bytes of scratch (fp32 slabs, added in split order:
  * deterministic).  No allocation, no sync. */
 int64_t msgl_wstream_gemm_workspace_bytes(int M, int N, int k_splits);
+/* msgl_wstream_gemm_nt with k_splits >= 2 WITHOUT its reduce launch: the fp32 slabs part[k_splits][M][N] stay in
+ * `workspace` for a slab-input consumer (msgl_fused_add_rmsnorm_slabs, msgl_qk_norm_rope_store_slabs), which adds them in
+ * split order and rounds -- the bits the reduce launch would have stored. */
+int msgl_wstream_gemm_slabs_nt(const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw, int dtype,
+                               int row_tiles, int k_splits, void* workspace, int64_t workspace_bytes, void* stream);
 int msgl_wstream_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
                          int64_t ldw, int64_t ldo, int dtype, int row_tiles, int k_splits,
                          void* workspace, int64_t workspace_bytes, void* stream);

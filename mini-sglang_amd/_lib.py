@@ -75,6 +75,7 @@ HIP_SIGNATURES = {
     "msgl_skinny_gemm_silu_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
     "msgl_wstream_gemm_workspace_bytes": (_l, [_i, _i, _i]),
     "msgl_wstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _l, _p]),
+    "msgl_wstream_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),
     "msgl_p2p_create": (_i, [C.POINTER(_p), _i, _i, _sz]),
     "msgl_p2p_ipc_handle": (_i, [_p, C.c_char_p]),
     "msgl_p2p_open": (_i, [_p, C.c_char_p]),

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void wstream_reduce_kernel(uint16_t* __restric
 
 template <typename T, int MT, int NT>
 static int launch_wstream_t(uint16_t* out, float* part, const uint16_t* x, const uint16_t* w, int M, int N, int K,
-                            int64_t ldx, int64_t ldw, int64_t ldo, int k_splits, hipStream_t s) {
+                            int64_t ldx, int64_t ldw, int64_t ldo, int k_splits, hipStream_t s, bool slabs_only) {
   const dim3 grid((unsigned)(N / (16 * NT * kWsWaves)), (unsigned)k_splits), block(64 * kWsWaves);
   const size_t lds = 2u * 16 * MT * kWsPitch;
   const int nsteps = K / kWsStepK;
@@ -219,6 +219,7 @@ static int launch_wstream_t(uint16_t* out, float* part, const uint16_t* x, const
     wstream_gemm_kernel<T, MT, NT, false><<<grid, block, lds, s>>>(out, nullptr, x, w, M, N, nsteps, ldx, ldw, ldo);
   } else {
     wstream_gemm_kernel<T, MT, NT, true><<<grid, block, lds, s>>>(out, part, x, w, M, N, nsteps, ldx, ldw, ldo);
+    if (slabs_only) return MSGL_OK;  // the consumer (a slab-input norm / qk pass) adds the slabs, in split order
     const int64_t threads = (int64_t)M * (N / 8);
     wstream_reduce_kernel<T><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(out, part, M, N, k_splits,
                                                                                           ldo);
@@ -228,11 +229,12 @@ static int launch_wstream_t(uint16_t* out, float* part, const uint16_t* x, const
 
 template <typename T>
 static int launch_wstream(uint16_t* out, float* part, const uint16_t* x, const uint16_t* w, int M, int N, int K,
-                          int64_t ldx, int64_t ldw, int64_t ldo, int row_tiles, int k_splits, hipStream_t s) {
+                          int64_t ldx, int64_t ldw, int64_t ldo, int row_tiles, int k_splits, hipStream_t s,
+                          bool slabs_only = false) {
   const int MT = M <= 64 ? 4 : M <= 128 ? 8 : 16;
 #define MSGL_WS(MT_, NT_) \
   if (MT == MT_ && row_tiles == NT_) \
-    return launch_wstream_t<T, MT_, NT_>(out, part, x, w, M, N, K, ldx, ldw, ldo, k_splits, s)
+    return launch_wstream_t<T, MT_, NT_>(out, part, x, w, M, N, K, ldx, ldw, ldo, k_splits, s, slabs_only)
   // (16, 2) -- 256 rows x two weight tiles per wave -- needs 128 accumulator registers on top of the four-deep weight
   // ring and spilled 91-96 VGPRs: not built; M > 128 takes one row tile (or the full-batch kernels of gemm_g3 / m256)
   MSGL_WS(4, 1); MSGL_WS(4, 2); MSGL_WS(8, 1); MSGL_WS(8, 2); MSGL_WS(16, 1);
@@ -284,5 +286,41 @@ extern "C" int msgl_wstream_gemm_nt(void* out, const void* x, const void* w, int
   }
   if (rc != MSGL_OK) return rc;
   MSGL_CHECK_LAUNCH("wstream_gemm_nt");
+  return MSGL_OK;
+}
+
+// The k-split product WITHOUT its reduce: fp32 slabs part[k_splits][M][N] in `workspace`, to be added in split order and
+// rounded by the consumer (msgl_fused_add_rmsnorm_slabs / msgl_qk_norm_rope_store_slabs), exactly what
+// msgl_wstream_gemm_nt's own reduce launch would have stored.  k_splits >= 2.
+extern "C" int msgl_wstream_gemm_slabs_nt(const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                                          int dtype, int row_tiles, int k_splits, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+  MSGL_REQUIRE(x && w && workspace, "wstream_gemm_slabs_nt: null pointer");
+  MSGL_REQUIRE(M >= 1 && M <= 256, "wstream_gemm_slabs_nt: M = %d outside [1, 256]", M);
+  MSGL_REQUIRE(row_tiles == 1 || row_tiles == 2, "wstream_gemm_slabs_nt: row_tiles %d (1, 2)", row_tiles);
+  MSGL_REQUIRE(N >= 128 * row_tiles && N % (128 * row_tiles) == 0, "wstream_gemm_slabs_nt: N = %d must be a multiple of %d",
+               N, 128 * row_tiles);
+  MSGL_REQUIRE(K >= kWsStepK && K % kWsStepK == 0, "wstream_gemm_slabs_nt: K = %d must be a multiple of %d", K, kWsStepK);
+  MSGL_REQUIRE(k_splits >= 2 && k_splits <= K / kWsStepK && k_splits <= 64, "wstream_gemm_slabs_nt: %d k splits", k_splits);
+  MSGL_REQUIRE(ldx >= K && ldw >= K && ldx % 8 == 0 && ldw % 8 == 0, "wstream_gemm_slabs_nt: leading dimensions (%lld, %lld)",
+               (long long)ldx, (long long)ldw);
+  MSGL_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace) &&
+                   workspace_bytes >= msgl_wstream_gemm_workspace_bytes(M, N, k_splits),
+               "wstream_gemm_slabs_nt: %d k splits need %lld aligned workspace bytes", k_splits,
+               (long long)msgl_wstream_gemm_workspace_bytes(M, N, k_splits));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (dtype == MSGL_BF16)
+    rc = launch_wstream<BF16>(nullptr, (float*)workspace, (const uint16_t*)x, (const uint16_t*)w, M, N, K, ldx, ldw, N,
+                              row_tiles, k_splits, s, true);
+  else if (dtype == MSGL_FP16)
+    rc = launch_wstream<FP16>(nullptr, (float*)workspace, (const uint16_t*)x, (const uint16_t*)w, M, N, K, ldx, ldw, N,
+                              row_tiles, k_splits, s, true);
+  else {
+    set_error("wstream_gemm_slabs_nt: unsupported dtype code %d", dtype);
+    return MSGL_EINVAL;
+  }
+  if (rc != MSGL_OK) return rc;
+  MSGL_CHECK_LAUNCH("wstream_gemm_slabs_nt");
   return MSGL_OK;
 }

@@ -896,8 +896,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
 
 def linear_slabs(x: torch.Tensor, w: torch.Tensor):
     """`linear` for a projection whose output feeds fused_add_rmsnorm directly: returns (out, slabs).  When the
-    shape's plan is the k-sliced full-batch kernel, the reduce launch is left to the norm (slabs is a Slabs, `out`
-    is allocated but NOT yet written: pass both to fused_add_rmsnorm_slabs); otherwise (out, None) = linear(x, w)."""
+    shape's plan is the k-sliced full-batch kernel (or, mid-size batches, the k-split weight-streaming kernel), the reduce
+    launch is left to the norm (slabs is a Slabs, `out` is allocated but NOT yet written: pass both to
+    fused_add_rmsnorm_slabs); otherwise (out, None) = linear(x, w)."""
     if x.shape[0] >= M256_MIN_M and _M256_PLAN:
         _no_pending_slabs(x.device)
         out, M, N, K = _gemm_args(x, w, None)
@@ -917,6 +918,24 @@ def linear_slabs(x: torch.Tensor, w: torch.Tensor):
                     "m256_gemm_slabs_nt",
                 )
             slabs = Slabs(ws.data_ptr(), plan[2], M, N, x.device.index or 0)
+            _PENDING_SLABS[slabs.device] = slabs
+            return out, slabs
+        if plan:  # a full-batch plan that writes its own output (whole tiles / one slice)
+            return linear(x, w, out), None
+    if x.shape[0] <= WSTREAM_MAX_M and _WSTREAM_PLAN and os.environ.get("MSGL_DISABLE_WSTREAM_SLABS") != "1":
+        # mid-size decode batches: the LDS-shared weight-streaming kernel's k splits, same hand-off (its reduce launch,
+        # ~5.5 us x 3 per layer at B = 64 .. 128, is left to the norm / qk pass that reads the output next)
+        out, M, N, K = _gemm_args(x, w, None)
+        plan = _WSTREAM_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan and plan[1] > 1 and not (M >= M256_MIN_M and _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))):
+            _no_pending_slabs(x.device)
+            ws = gemm_workspace(x.device)
+            check(
+                lib().msgl_wstream_gemm_slabs_nt(x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), _dt(x),
+                                                 plan[0], plan[1], ws.data_ptr(), ws.numel(), _stream()),
+                "wstream_gemm_slabs_nt",
+            )
+            slabs = Slabs(ws.data_ptr(), plan[1], M, N, x.device.index or 0)
             _PENDING_SLABS[slabs.device] = slabs
             return out, slabs
         return linear(x, w, out), None

@@ -430,6 +430,43 @@ def test_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, 
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,nt,split", [(128, 5120, 5120, 2, 4), (64, 5120, 17408, 1, 8), (96, 1024, 3072, 1, 3), (33, 256, 640, 2, 2),
+                                           (200, 640, 1024, 1, 6)])
+def test_wstream_split_k_reduce_folded_into_fused_add_rmsnorm(ops, dev, dtype, M, N, K, nt, split):
+    """Mid-size decode batches: the LDS-shared weight-streaming kernel's k splits handed to the norm the same way as the
+    full-batch kernels' (no reduce launch): x and residual bit-identical to the kernel's own reduce followed by the norm."""
+    from mini_sglang_amd import flashinfer_compat as fi
+
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(dtype)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(dtype)
+    res0 = torch.randn((M, N), generator=g, device=dev).to(dtype)
+    nw = (1 + 0.1 * torch.randn(N, generator=g, device=dev)).to(dtype)
+    key = (dev.index or 0, M, N, K, x.stride(0), w.stride(0), ops._dt(x))
+    ops._WSTREAM_PLAN[key] = (nt, split)
+    try:
+        y_ref, r_ref = ops.linear(x, w), res0.clone()
+        assert torch.equal(y_ref, ops.wstream_linear(x, w, nt, split))
+        ops.fused_add_rmsnorm(y_ref, r_ref, nw, 1e-6)
+        y, slabs = ops.linear_slabs(x, w)
+        assert slabs is not None and slabs.count == split
+        with pytest.raises(RuntimeError, match="partial sums"):
+            ops.linear(x, w)                    # workspace still owed to the norm (reported once, the hand-off is then void)
+        y, slabs = ops.linear_slabs(x, w)
+        y._msgl_slabs = slabs
+        r = res0.clone()
+        fi.fused_add_rmsnorm(y, r, nw, 1e-6)
+        assert torch.equal(y, y_ref) and torch.equal(r, r_ref)
+        ops.linear(x, w)
+        ops._WSTREAM_PLAN[key] = (nt, 1)       # no k split: nothing to hand over
+        y2, none = ops.linear_slabs(x, w)
+        assert none is None and torch.equal(y2, ops.wstream_linear(x, w, nt, 1))
+    finally:
+        ops._WSTREAM_PLAN.clear()
+        ops._PENDING_SLABS.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,hq,hk,D,K,split,qk_norm", [(256, 40, 8, 128, 5120, 4, True), (160, 16, 8, 128, 1024, 4, True),
                                                      (130, 8, 2, 64, 512, 2, False)])
 @pytest.mark.parametrize("impl", [0, 1])
