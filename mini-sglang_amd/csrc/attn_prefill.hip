@@ -1,9 +1,11 @@
 // Paged varlen causal prefill attention for gfx950 (MFMA 32x32x16, fp32 accumulate).
 //
-// One workgroup = 4 waves = one 128-row query tile of one (request, q head); each wave owns 32
-// query rows.  K/V are gathered through the reference's token-granular page table in 64-key
-// tiles, staged global -> registers -> LDS one tile ahead of the MFMAs (loads issued before the
-// tile's compute, LDS written after it).
+// Four kernel generations with the same math per query row (impl codes in include/msgl_hip.h); the default is the
+// DMA-staged one (attn_prefill_dma_kernel).  Common to all but the last: one workgroup = 4 waves = one 128-row query
+// tile of one (request, q head); each wave owns 32 query rows.  K/V are gathered through the reference's
+// token-granular page table in 64-key tiles one tile ahead of the MFMAs: global -> registers -> LDS in the first two
+// generations, global -> LDS by DMA (global_load_lds_dwordx4) in the third; the fourth (attn_prefill_pp_kernel) runs two
+// wave groups of a 256-row tile in counter-phase (matrix segment beside softmax segment).
 //
 // Data flow per 64-key tile and wave (all in registers except the K/V tile):
 //   S^T = K . Q^T   ("swapped" QK^T: A = K rows from LDS (XOR-swizzled, conflict-free
