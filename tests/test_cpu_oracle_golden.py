@@ -257,6 +257,17 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.msgl_attn_decode_plan_words(8, 64) == 96 + 256 + 256 + 8 * 64  # + arrival counters: 8 requests x 64 kv heads
     assert L.msgl_attn_decode_workspace_bytes(64, 40, 128) == 64 * 40 * 130 * 4
     assert L.msgl_fast_compare_key(None, 3, None, 3, 4) == -1
+    # round-3 entry points: tile rows per prefill kernel, fused gate_up + SiLU.mul, slab-only weight-streaming GEMM
+    assert L.msgl_attn_prefill_q_tile(0) == 128 and L.msgl_attn_prefill_q_tile(4) == 128 and L.msgl_attn_prefill_q_tile(5) == 256
+    assert L.msgl_attn_prefill(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 1, 1, 8, 2, 128, 1024, 256, 128, 1024, 0.1,
+                               0, None, 7, None) == -1  # unknown kernel code
+    assert L.msgl_attn_prefill(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 1, 1, 8, 2, 128, 1024, 1 << 33, 128, 1024,
+                               0.1, 0, None, 0, None) == -1  # token stride beyond the 32-bit slot-offset multiply
+    assert L.msgl_skinny_gemm_silu_nt(p16, p16, p16, 4, 256, 128, 128, 128, 128, 0, 2, 3, None) == -1  # row tiles 1, 2, 4
+    assert L.msgl_skinny_gemm_silu_nt(p16, p16, p16, 4, 96, 128, 128, 128, 128, 0, 2, 2, None) == -1   # gate / up blocks of 32 rows
+    assert L.msgl_skinny_gemm_silu_nt(p16, p16, p16, 4, 256, 128, 128, 128, 64, 0, 2, 2, None) == -1   # ldo < N / 2
+    assert L.msgl_wstream_gemm_slabs_nt(p16, p16, 64, 256, 128, 128, 128, 0, 1, 1, p16, 1 << 20, None) == -1  # needs >= 2 k splits
+    assert L.msgl_wstream_gemm_slabs_nt(p16, p16, 64, 256, 128, 128, 128, 0, 1, 2, p16, 1024, None) == -1     # workspace too small
     with pytest.raises(RuntimeError):
         from mini_sglang_amd import ops
 
