@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: decode tokens/s of the MI355X paged-attention serving core.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W        (N > 1: TP = N over RCCL)
+        --master-port P bench.py --gpus N --steps K --warmup W        (N > 1: TP = N, one rank per GPU)
 
 Workload (BASELINE.json: metric quoted on Qwen3-14B TP=1; fits one GPU => configs[2]'s model on
 configs[1]'s request shape): Qwen3-14B bf16, 256 sequences, context lengths drawn from the
@@ -51,61 +51,51 @@ def bench_contexts(num_seqs: int, seed: int = 0):
     return [ins[r] + pick.randint(0, outs[r] - 1) for r in reqs]
 
 
-def cpu_baseline(cfg, contexts, seconds_budget: float = 25.0):
-    """Oracle (oracle/ref_model.py) timed on the host cores: `layers_s` decoder layers + LM head of
-    the SAME model dims at a reduced batch, extrapolated to the full depth.  A reported baseline,
-    not a target."""
-    from oracle import ref_model, ref_ops
+def cpu_baseline(cfg, contexts, rounds: int = 3):
+    """Oracle (oracle/ref_model.py, torch eager fp32) timed on the host cores ON THE GPU WORKLOAD'S SHAPE: ONE decoder
+    layer of the same dims at the full batch (256 requests, the bench's own contexts, K/V gathered through a page
+    table) + embedding, final norm and LM head, x num_layers.  A reported baseline, not a target."""
+    from oracle import ref_model
 
-    # a many-socket host thrashes when torch spreads an M=8 GEMV over every hardware thread
-    # (measured: 256 threads => 470 s/step); cap, and report the threads actually used
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MSGL_CPU_BASELINE_THREADS", "32")))
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MSGL_CPU_BASELINE_THREADS", "64")))
     torch.set_num_threads(cores)
-    B, L = 8, 2
-    lens = contexts[:B]
+    B, L = len(contexts), 1
+    lens = [int(n) for n in contexts]
     D = cfg.head_dim
     g = torch.Generator().manual_seed(0)
+    small_vocab = 4096  # the embedding table is only gathered from: a small one keeps the host allocation bounded
     w = ref_model.random_weights(
-        type("C", (), dict(cfg.__dict__, vocab_size=10000, tie_word_embeddings=True))(), torch.float32, num_layers=L)
-    lm_head = torch.randn((cfg.vocab_size, cfg.hidden_size), generator=g) * 0.02
-    w.lm_head = lm_head
-    max_len = max(lens) + 8
-    slots = B * max_len
-    table = torch.arange(slots, dtype=torch.int32).view(B, max_len)
-    kp = [torch.randn((slots, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
-    vp = [torch.randn((slots, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
-    ids = torch.randint(0, 10000, (B,), generator=g)
+        type("C", (), dict(cfg.__dict__, vocab_size=small_vocab, tie_word_embeddings=True))(), torch.float32, num_layers=L)
+    w.lm_head = torch.randn((cfg.vocab_size, cfg.hidden_size), generator=g) * 0.02
+    row = max(lens) + rounds + 2
+    table = torch.arange(B * row, dtype=torch.int32).view(B, row)
+    kp = [torch.randn((B * row, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
+    vp = [torch.randn((B * row, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
+    ids = torch.randint(0, small_vocab, (B,), generator=g)
+    no_head = ref_model.CpuWeights(w.embed, w.layers, w.final_norm, w.lm_head[:8], w.cos_sin)
 
-    def step(cur):
+    def run(weights, cur):
         pos = torch.tensor([n - 1 for n in cur], dtype=torch.int32)
         loc = table[torch.arange(B), pos.long()]
-        return ref_model.forward(cfg, w, ids, pos, loc, kp, vp, table, list(range(B)), cur, [1] * B, False)
+        t0 = time.perf_counter()
+        ref_model.forward(cfg, weights, ids, pos, loc, kp, vp, table, list(range(B)), cur, [1] * B, False)
+        return time.perf_counter() - t0
 
-    def layers_only(cur):
-        pos = torch.tensor([n - 1 for n in cur], dtype=torch.int32)
-        loc = table[torch.arange(B), pos.long()]
-        w2 = ref_model.CpuWeights(w.embed, w.layers, w.final_norm, w.lm_head[:8], w.cos_sin)
-        return ref_model.forward(cfg, w2, ids, pos, loc, kp, vp, table, list(range(B)), cur, [1] * B, False)
-
-    step(lens)  # warm-up
-    t_full, t_lay = [], []
-    t_start = time.perf_counter()
-    for i in range(5):
+    run(no_head, lens)  # warm-up (thread pool, allocator)
+    t_layer, t_full = [], []
+    for i in range(rounds):
         cur = [n + i + 1 for n in lens]
-        t0 = time.perf_counter(); step(cur); t1 = time.perf_counter()
-        layers_only(cur); t2 = time.perf_counter()
-        t_full.append(t1 - t0); t_lay.append(t2 - t1)
-        if time.perf_counter() - t_start > seconds_budget:
-            break
-    t_full.sort(); t_lay.sort()
-    full, lay = t_full[len(t_full) // 2], t_lay[len(t_lay) // 2]
-    per_layer = lay / L
-    head = max(full - lay, 0.0)
-    est_step = per_layer * cfg.num_layers + head
+        t_layer.append(run(no_head, cur))  # embedding + L layers + final norm + an 8-row LM head
+        t_full.append(run(w, cur))         # the same with the full LM head
+    t_layer.sort(); t_full.sort()
+    lay = t_layer[len(t_layer) // 2]
+    head = max(t_full[len(t_full) // 2] - lay, 0.0)
+    est_step = lay * cfg.num_layers / L + head
     return dict(value=B / est_step, unit="tokens/s", cores=cores, kind="port",
-                sample=f"torch-eager oracle, {cfg.name} dims, batch {B} (contexts {lens}), {L} of "
-                       f"{cfg.num_layers} layers + LM head timed ({len(t_full)} steps, median), extrapolated "
-                       f"to {cfg.num_layers} layers: {est_step * 1e3:.0f} ms/step")
+                sample=f"torch-eager fp32 oracle, {cfg.name} dims, the GPU step's own batch: {B} requests, contexts mean "
+                       f"{sum(lens) / B:.0f} through a page table; {L} of {cfg.num_layers} decoder layers timed "
+                       f"({lay * 1e3:.0f} ms, median of {rounds}) x {cfg.num_layers // L} + embedding / final norm / LM head "
+                       f"({head * 1e3:.0f} ms): {est_step * 1e3:.0f} ms/step")
 
 
 def pmc_traffic(attn_bytes: int, shape: str):
@@ -166,44 +156,52 @@ def measure_prefill_attention(device, hq: int, hkv: int, budget: int = 16384):
             "flops": c["flops"], "chunk_tokens": c["T"], "requests": c["B"]}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="qwen3-14b")
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--page-size", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end README offline benchmark (extra keys)")
-    ap.add_argument("--no-prefill", action="store_true", help="fill the KV pool with random data instead")
-    ap.add_argument("--no-prefill-roofline", action="store_true", help="skip the prefill-attention MFMA measurement")
-    ap.add_argument("--small-batches", type=int, nargs="*", default=[1, 8, 32],
-                    help="also report ms per decode step at these batch sizes (latency regime; [] to skip)")
-    ap.add_argument("--rank-shard", type=int, default=0,
-                    help="N > 1: time ONE rank's shard of a TP = N decode step on this GPU with the collectives looped back "
-                         "(tools/rank_shard_bench.py): an upper bound on the TP = N speed-up before any link is paid")
-    ap.add_argument("--tp1-ms", type=float, default=None, help="with --rank-shard: the TP1 ms/step to compare against")
-    args = ap.parse_args()
-    if args.rank_shard > 1:
-        from tools.rank_shard_bench import main as rank_shard_main
+def self_launch(gpus: int) -> int:
+    """`python3 bench.py --gpus N` with no launcher around it: start the N ranks through torch.distributed.run (one
+    process per GPU, loopback rendezvous on a free port) and hand back its exit code; rank 0's JSON line goes to this
+    process's stdout."""
+    import socket
+    import subprocess
 
-        argv = ["--model", args.model, "--tp", str(args.rank_shard), "--batch", str(args.batch), "--steps", str(args.steps),
-                "--warmup", str(args.warmup), "--page-size", str(args.page_size)]
-        rank_shard_main(argv + (["--tp1-ms", str(args.tp1_ms)] if args.tp1_ms else []))
-        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MSGL_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
-    # MSGL_BENCH_SHARE_GPU=1: every rank on cuda:0 with the peer-to-peer communicator only (RCCL refuses two ranks per
-    # device) -- exercises the whole N > 1 code path of this file on a 1-GPU box; not a measurement
-    share_gpu = os.environ.get("MSGL_BENCH_SHARE_GPU") == "1"
-    device = torch.device("cuda:0" if share_gpu else f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
 
+def check_collectives(comm, rank: int, world: int, device) -> dict:
+    """Known answers on the links the run is about to use, and what the libraries themselves report: rank-valued data ->
+    n(n+1)/2 through RCCL directly (whatever the hybrid dispatch would pick for the size) and `ncclCommCount` as
+    `rccl_ranks_seen`; the peer-to-peer kernels were checked the same way by init_pynccl (kernel.P2PCommunicator.
+    self_test) -- a failure there leaves comm.p2p None and RCCL carries every message."""
+    import torch.distributed as dist
+
+    out = {"p2p": "ok (one-shot / two-shot / all-gather known answers)" if comm.p2p is not None else "absent: RCCL carries every message"}
+    if comm.rccl is not None:
+        info = comm.rccl.info()
+        x = torch.full((1 << 20,), float(rank + 1), dtype=torch.bfloat16, device=device)
+        comm.rccl.all_reduce(x)
+        torch.cuda.synchronize(device)
+        ok = bool((x == float(world * (world + 1) // 2)).all())
+        devs = [None] * world
+        dist.all_gather_object(devs, (info["nranks"], info["device"], ok))
+        out.update(rccl_ranks_seen=min(d[0] for d in devs), rccl_devices=[d[1] for d in devs],
+                   rccl_known_answer_ok=all(d[2] for d in devs))
+    else:
+        out.update(rccl_ranks_seen=0, rccl_devices=[], rccl_known_answer_ok=None)
+    return out
+
+
+def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, device, share_gpu: bool,
+                 primary: bool) -> dict:
+    """One decode workload (chunked prefill, W + K decode steps, roofline of the attention launch) of `model_name` at
+    TP = world.  primary: the headline entry (with the latency regime, the prefill-attention roofline, the GEMM search
+    report); a secondary entry (Qwen3-32B at --gpus 4) carries the step time, TTFT and the collectives report only."""
     from mini_sglang_amd import ops
     from mini_sglang_amd.core import SamplingParams
     from mini_sglang_amd.engine import Engine, EngineConfig
@@ -212,37 +210,32 @@ def main() -> None:
 
     import torch.distributed as dist
 
+    mcfg = PRESETS[model_name]
     comm = comm_side = None
+    collectives = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one node: rendezvous and the RCCL bootstrap over loopback (the box's hostname may not resolve);
-        # the data path is xGMI peer-to-peer either way
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         from mini_sglang_amd.kernel import init_pynccl
 
         # decode-size messages (all-reduce [B, hidden], logits all-gather [B, V / tp]) go peer to peer over mapped
         # buffers, prefill-size ones through RCCL; a second communicator serves the side stream
-        p2p_bytes = max(args.batch * PRESETS[args.model].hidden_size * 2,
-                        args.batch * (-(-PRESETS[args.model].vocab_size // world)) * 2)
+        p2p_bytes = max(args.batch * mcfg.hidden_size * 2, args.batch * (-(-mcfg.vocab_size // world)) * 2)
         if share_gpu:  # every message must fit the mapped buffers: size them for a prefill chunk as well
-            p2p_bytes = max(p2p_bytes, 16384 * PRESETS[args.model].hidden_size * 2)
-        backend = "p2p" if share_gpu else "hybrid"
+            p2p_bytes = max(p2p_bytes, 16384 * mcfg.hidden_size * 2)
+        backend = "p2p" if share_gpu else os.environ.get("MSGL_COMM_BACKEND", "hybrid")
         comm = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=p2p_bytes, backend=backend)
         comm_side = init_pynccl(tp_rank=rank, tp_size=world, tp_cpu_group=dist.group.WORLD, max_size_bytes=p2p_bytes,
                                 backend=backend)
+        collectives = check_collectives(comm, rank, world, device)
 
     def barrier():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
 
-    mcfg = PRESETS[args.model]
     B = args.batch
     # the latency-regime section is a single-GPU extra: under TP every additional graph is another capture
     # with collectives inside, which the headline measurement does not need
-    small_batches = list(args.small_batches) if world == 1 else []
+    small_batches = list(args.small_batches) if (world == 1 and primary) else []
     contexts = bench_contexts(B)
     use_graph = os.environ.get("MSGL_BENCH_NO_GRAPH", "0") != "1"
     max_seq = 4096  # max_seq_len_override of the reference bench
@@ -261,6 +254,13 @@ def main() -> None:
         if not use_graph:
             raise
         err = f"{type(e).__name__}: {e}"
+    if world > 1:  # every rank must take the same path: one rank falling back to eager alone would desynchronise the collectives
+        flags = [None] * world
+        dist.all_gather_object(flags, err)
+        err = next((f for f in flags if f), None)
+        if err is not None and engine is not None:
+            engine.shutdown()
+            engine = None
     if engine is None:
         # outside the except block: the failed engine (weights + 0.9 of HBM as KV pool) is only
         # referenced by the dead traceback; drop it before sizing a second pool
@@ -371,21 +371,21 @@ def main() -> None:
                 runner.decode_step(sub)
             barrier()
             small[str(sb)] = (time.perf_counter() - t1) * 1e3 / 10
-        if world > 1:
-            for k in list(small):
-                t = torch.tensor([small[k]], dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                small[k] = float(t[0])
 
-    shape = f"{args.model} tp{world} B{B} page{args.page_size} bench_contexts"
+    shape = f"{model_name} tp{world} B{B} page{args.page_size} bench_contexts"
     traffic, traffic_src, traffic_ratio = pmc_traffic(attn_bytes, shape)
     prefill_roofline = None
-    if rank == 0 and not args.no_prefill_roofline:
+    if rank == 0 and primary and not args.no_prefill_roofline:
         try:
             prefill_roofline = measure_prefill_attention(device, hq, hkv)
         except Exception as e:  # never lose the headline numbers to the side measurement
             prefill_roofline = {"error": f"{type(e).__name__}: {e}"}
 
+    if collectives is not None:
+        collectives["issued_from_python"] = dict(comm.issued, note="collectives issued per path; a launch captured into the decode "
+                                                 "graph counts once (at capture), prefill chunks run eager")
+        collectives["paths"] = ("p2p only, all ranks on ONE gpu (code-path check)" if share_gpu else
+                                "p2p (decode-size) + rccl (prefill-size)" if comm.p2p is not None else "rccl")
     result = {
         "metric": METRIC, "value": tokens_per_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
@@ -395,8 +395,7 @@ def main() -> None:
                         f"distribution (mean {S / B:.0f}), page_size {args.page_size}, temperature 0.6, hipGraph "
                         f"{'on' if use_graph else 'off'}",
             "batch": B, "parallelism": f"tp{world}", "mean_context": S / B,
-            "collectives": None if world == 1 else ("p2p only, all ranks on ONE gpu (code-path check)" if share_gpu else
-                                                    "p2p (decode-size) + rccl" if comm.p2p is not None else "rccl"),
+            "collectives": None if world == 1 else collectives["paths"],
         },
         "ttft_p50_ms": ttft_p50,
         "small_batch_ms_per_step": small,
@@ -410,11 +409,13 @@ def main() -> None:
         "step_roofline": {
             "bound": "hbm", "bytes_per_step_per_rank": step_bytes, "achieved": step_gbps, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": step_gbps / HBM_PEAK_GBPS,
-            "roofline_tokens_per_s": B * HBM_PEAK_GBPS * 1e9 / step_bytes * (1 if world == 1 else 1),
+            "roofline_tokens_per_s": B * HBM_PEAK_GBPS * 1e9 / step_bytes,
         },
     }
+    if collectives is not None:
+        result["collectives"] = collectives
     # projection GEMMs at the full batch: weight bytes over the search's back-to-back times (what the kernels sustain on
-    # their own; inside the step the consumers of their slabs are part of the cost: profiles/r03*_kernel_breakdown.txt)
+    # their own; inside the step the consumers of their slabs are part of the cost: profiles/r0*_kernel_breakdown.txt)
     full = [r for r in engine.gemm_report if r["M"] == B]
     if full:
         L = mcfg.num_layers
@@ -422,23 +423,112 @@ def main() -> None:
         us = sum(r["best_us"] * (1 if r["name"] == "lm_head" else L) for r in full)
         result["step_roofline"]["gemm_weight_TBps"] = wbytes / us / 1e6
         result["step_roofline"]["gemm_ms_per_step_back_to_back"] = us / 1e3
-    ratio, src = gemm_traffic_over_algorithmic()
-    result["step_roofline"]["gemm_traffic_over_algorithmic"] = ratio
-    result["step_roofline"]["gemm_traffic_source"] = src
+    if primary and world == 1:
+        ratio, src = gemm_traffic_over_algorithmic()
+        # "committed": from the rocprofv3 PMC passes kept under profiles/ (counters cannot be read from inside this process)
+        result["step_roofline"]["gemm_traffic_over_algorithmic"] = {"kind": "committed", "value": ratio, "source": src}
     # library GEMM solution search done at engine start (csrc/gemm.cpp): heuristic pick vs chosen, per launch
-    result["gemm_tune"] = {
-        "mode": ecfg.gemm_tune,
-        "shapes": [dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], heuristic_us=round(r["default_us"], 1),
-                        tuned_us=round(r["best_us"], 1), candidates=r["tried"],
-                        tflops=round(2.0 * r["M"] * r["N"] * r["K"] / r["best_us"] / 1e6, 1),
-                        weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2),
-                        **({"hand_written": r["kernel"], "library_best_us": round(r["library_best_us"], 1)}
-                           if r.get("skinny_used") else {}),
-                        **({"projection_then_silu_us": round(r["silu_unfused_us"], 1),
-                            "fused_silu_epilogue_us": round(r["silu_fused_us"], 1), "fused_silu_used": r["silu_fused_used"]}
-                           if r.get("silu_fused_us") else {})) for r in engine.gemm_report],
-    }
-    result["gemm_tune"]["refined_in_graph"] = getattr(engine, "refine_report", [])
+    if primary:
+        result["gemm_tune"] = {
+            "mode": ecfg.gemm_tune,
+            "shapes": [dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], heuristic_us=round(r["default_us"], 1),
+                            tuned_us=round(r["best_us"], 1), candidates=r["tried"],
+                            tflops=round(2.0 * r["M"] * r["N"] * r["K"] / r["best_us"] / 1e6, 1),
+                            weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2),
+                            **({"hand_written": r["kernel"], "library_best_us": round(r["library_best_us"], 1)}
+                               if r.get("skinny_used") else {}),
+                            **({"projection_then_silu_us": round(r["silu_unfused_us"], 1),
+                                "fused_silu_epilogue_us": round(r["silu_fused_us"], 1), "fused_silu_used": r["silu_fused_used"]}
+                               if r.get("silu_fused_us") else {})) for r in engine.gemm_report],
+        }
+        result["gemm_tune"]["refined_in_graph"] = getattr(engine, "refine_report", [])
+    else:
+        result["gemm_plans_at_full_batch"] = {r["name"]: dict(us=round(r["best_us"], 1), kernel=r["kernel"][:70]) for r in full}
+    engine.shutdown()  # raises if a peer-to-peer barrier ever timed out (NaN-poisoned collectives)
+    del runner, states, running, be, k_tok, v_tok, launch, engine, q, o
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    for c in (comm, comm_side):
+        if c is not None:
+            c.destroy()
+    return result
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="qwen3-14b")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--page-size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end README offline benchmark (extra keys)")
+    ap.add_argument("--no-prefill", action="store_true", help="fill the KV pool with random data instead")
+    ap.add_argument("--no-prefill-roofline", action="store_true", help="skip the prefill-attention MFMA measurement")
+    ap.add_argument("--no-second-config", action="store_true",
+                    help="--gpus 4: skip the Qwen3-32B TP4 entry (the metric's second configuration)")
+    ap.add_argument("--small-batches", type=int, nargs="*", default=[1, 8, 32],
+                    help="also report ms per decode step at these batch sizes (latency regime; [] to skip)")
+    ap.add_argument("--rank-shard", type=int, default=0,
+                    help="N > 1: time ONE rank's shard of a TP = N decode step on this GPU with the collectives looped back "
+                         "(tools/rank_shard_bench.py): an upper bound on the TP = N speed-up before any link is paid")
+    ap.add_argument("--tp1-ms", type=float, default=None, help="with --rank-shard: the TP1 ms/step to compare against")
+    args = ap.parse_args()
+    if args.rank_shard > 1:
+        from tools.rank_shard_bench import main as rank_shard_main
+
+        argv = ["--model", args.model, "--tp", str(args.rank_shard), "--batch", str(args.batch), "--steps", str(args.steps),
+                "--warmup", str(args.warmup), "--page-size", str(args.page_size)]
+        rank_shard_main(argv + (["--tp1-ms", str(args.tp1_ms)] if args.tp1_ms else []))
+        return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us (the driver's `python3 bench.py --gpus N`): start the ranks ourselves
+        sys.exit(self_launch(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU fallback)"
+    # MSGL_BENCH_SHARE_GPU=1: every rank on cuda:0 with the peer-to-peer communicator only (RCCL refuses two ranks per
+    # device) -- exercises the whole N > 1 code path of this file on a 1-GPU box; not a measurement
+    share_gpu = os.environ.get("MSGL_BENCH_SHARE_GPU") == "1"
+    if not share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible "
+                         f"(MSGL_BENCH_SHARE_GPU=1 runs all ranks on one device as a code-path check)")
+    device = torch.device("cuda:0" if share_gpu else f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    import torch.distributed as dist
+
+    from mini_sglang_amd.model import PRESETS
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one node: rendezvous and the RCCL bootstrap over loopback (the box's hostname may not resolve);
+        # the data path is xGMI peer-to-peer either way
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    result = run_workload(args, args.model, rank, local_rank, world, device, share_gpu, primary=True)
+    result["launch"] = ("self-launched: bench.py started its ranks through torch.distributed.run"
+                        if os.environ.get("MSGL_BENCH_SELF_LAUNCHED") == "1" else
+                        "external launcher (torchrun)" if world > 1 else "single process")
+    mcfg = PRESETS[args.model]
+    contexts = bench_contexts(args.batch)
+    ms_per_step = result["ms_per_step"]
+    if world == 4 and args.model == "qwen3-14b" and not args.no_second_config:
+        # the metric's second configuration (BASELINE.json: "Qwen3-32B TP=4"): the same request set on Qwen3-32B
+        try:
+            r32 = run_workload(args, "qwen3-32b", rank, local_rank, world, device, share_gpu, primary=False)
+            result["qwen3_32b_tp4"] = {k: r32[k] for k in ("value", "unit", "ms_per_step", "ttft_p50_ms", "config", "roofline",
+                                                            "step_roofline", "collectives", "gemm_plans_at_full_batch") if k in r32}
+        except Exception as e:
+            result["qwen3_32b_tp4"] = {"error": f"{type(e).__name__}: {e}"}
     # what the REFERENCE's own LLM / Scheduler / GraphRunner measure on this path through the plugin: recorded by
     # tests/test_gpu_reference_driven.py (it may import oracle/_ref, this file may not) and committed under profiles/
     ref_runs = sorted((ROOT / "profiles").glob("r*_refdrive_14b.json"))
@@ -452,13 +542,6 @@ def main() -> None:
                                           "driver": d["driver"], "source": f"profiles/{ref_runs[-1].name}"}
         except Exception as e:
             result["reference_driven"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_e2e):
-        engine.shutdown()
-        del runner, states, running, be, k_tok, v_tok, launch, engine
-        import gc
-
-        gc.collect()
-        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_e2e:
         # the reference's own throughput definition (benchmark/offline/bench.py:32-38): sum(max_tokens) / wall of one
         # generate() over 256 requests, in/out 100..1024, prefill included, one untimed warm-up -- BASELINE configs 1, 2
@@ -481,10 +564,6 @@ def main() -> None:
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
-        engine.shutdown()  # raises if a peer-to-peer barrier ever timed out (NaN-poisoned collectives)
-        for c in (comm, comm_side):
-            if c is not None:
-                c.destroy()
         dist.destroy_process_group()
 
 

@@ -433,6 +433,8 @@ int msgl_comm_all_reduce_sum(msgl_comm_t comm, void* data, size_t count, int dty
 int msgl_comm_all_gather(msgl_comm_t comm, void* dst, const void* src, size_t count, int dtype,
                          void* stream);
 void* msgl_comm_get_buffer(msgl_comm_t comm);
+/* ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the communicator (any pointer may be NULL) */
+int msgl_comm_info(msgl_comm_t comm, int* nranks, int* rank, int* device);
 int msgl_comm_destroy(msgl_comm_t comm);
 const char* msgl_comm_last_error(void);
 

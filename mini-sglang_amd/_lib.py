@@ -110,6 +110,7 @@ COMM_SIGNATURES = {
     "msgl_comm_all_reduce_sum": (_i, [_p, _p, _sz, _i, _p]),
     "msgl_comm_all_gather": (_i, [_p, _p, _p, _sz, _i, _p]),
     "msgl_comm_get_buffer": (_p, [_p]),
+    "msgl_comm_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "msgl_comm_destroy": (_i, [_p]),
     "msgl_comm_last_error": (C.c_char_p, []),
 }

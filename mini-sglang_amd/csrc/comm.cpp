@@ -148,6 +148,20 @@ int msgl_comm_all_gather(msgl_comm_t c, void* dst, const void* src, size_t count
 
 void* msgl_comm_get_buffer(msgl_comm_t c) { return c ? c->buf : nullptr; }
 
+// What the library itself reports for this communicator (not what the caller passed to create): bench.py prints
+// nranks as `rccl_ranks_seen`, so that an N-GPU line shows the collective really spans N ranks on N devices.
+int msgl_comm_info(msgl_comm_t c, int* nranks, int* rank, int* device) {
+  if (!c || !c->comm) { set_err("comm_info: null communicator"); return MSGL_EINVAL; }
+  int n = 0, r = 0, d = 0;
+  COMM_NCCL(ncclCommCount(c->comm, &n), "ncclCommCount");
+  COMM_NCCL(ncclCommUserRank(c->comm, &r), "ncclCommUserRank");
+  COMM_NCCL(ncclCommCuDevice(c->comm, &d), "ncclCommCuDevice");
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
+  return MSGL_OK;
+}
+
 int msgl_comm_destroy(msgl_comm_t c) {
   if (!c) return MSGL_OK;
   if (c->reg_handle) (void)ncclCommDeregister(c->comm, c->reg_handle);

@@ -66,6 +66,13 @@ class RcclCommunicator:
     def get_buffer(self) -> int:
         return int(self._lib.msgl_comm_get_buffer(self._handle) or 0)
 
+    def info(self) -> dict:
+        """What RCCL itself reports for this communicator: ranks in it, this rank, the device it is bound to."""
+        n, r, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check_comm(self._lib.msgl_comm_info(self._handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)),
+                        "comm_info")
+        return dict(nranks=n.value, rank=r.value, device=d.value)
+
     def destroy(self) -> None:
         if self._handle:
             self._lib.msgl_comm_destroy(self._handle)
@@ -255,22 +262,34 @@ class HybridCommunicator:
         # a second, independent communicator for collectives issued on a side stream while this one is busy on the
         # compute stream (minisgl_plugin's row-parallel overlap); None unless init_pynccl(side=True) made one
         self.side: Optional["HybridCommunicator"] = None
+        # collectives ISSUED from Python per path (a launch captured into a hipGraph is counted once, at capture, not
+        # per replay): bench.py reports the split next to `rccl_ranks_seen`
+        self.issued = dict(p2p_calls=0, p2p_bytes=0, rccl_calls=0, rccl_bytes=0)
         _LIVE_COMMUNICATORS.add(self)
+
+    def _count(self, path: str, t: torch.Tensor) -> None:
+        self.issued[path + "_calls"] += 1
+        self.issued[path + "_bytes"] += t.numel() * t.element_size()
 
     def all_reduce(self, input: torch.Tensor, op: Literal["sum"] = "sum") -> None:
         if self.p2p is not None and (self.rccl is None or self.p2p.fits(input)):
+            self._count("p2p", input)
             return self.p2p.all_reduce(input, op)
+        self._count("rccl", input)
         return self.rccl.all_reduce(input, op)
 
     def all_gather(self, output: torch.Tensor, input: torch.Tensor) -> None:
         if self.p2p is not None and (self.rccl is None or self.p2p.fits(input)):
+            self._count("p2p", input)
             return self.p2p.all_gather(output, input)
+        self._count("rccl", input)
         return self.rccl.all_gather(output, input)
 
     def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
         """all_reduce(x) followed by fused_add_rmsnorm(x, residual, weight, eps): one peer-to-peer launch where that
         kernel applies (decode-size row blocks), else the two operations."""
         if self.p2p is not None and self.p2p.all_reduce_add_rmsnorm(x, residual, weight, eps):
+            self._count("p2p", x)
             return
         self.all_reduce(x, "sum")
         ops.fused_add_rmsnorm(x, residual, weight, eps)
