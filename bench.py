@@ -288,7 +288,7 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
         runner.warmup_prefill()
     barrier()
     if args.no_prefill:
-        engine.kv_cache._kv_buffer.normal_(0.0, 1.0)
+        engine.kv_cache.pool.normal_(0.0, 1.0)
         for st in states:
             st.req.cached_len, st.req.device_len = st.prompt_len - 1, st.prompt_len
         runner._allocate_paged([type("R", (), dict(table_idx=s.req.table_idx, cached_len=0,

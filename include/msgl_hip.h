@@ -46,7 +46,7 @@ extern "C" {
 /* dtype codes for logits */
 #define MSGL_F32 2
 
-#define MSGL_ABI_VERSION 3
+#define MSGL_ABI_VERSION 4
 
 /* Last error message of the calling thread ("" if none). */
 const char* msgl_last_error(void);
@@ -233,18 +233,14 @@ int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void*
                       float sm_scale, int dtype, const int32_t* tile_order, int impl, void* stream);
 /* tile_order (device, [total_tiles], may be NULL = natural order): the order in which q tiles are
  * scheduled -- the host passes tiles sorted by decreasing key count so the launch tail is made of light
- * tiles (results do not depend on it).  impl: 0 = default, 1 = first-generation kernel (V transposed
- * while staging), 2 = ds_read_b64_tr_b16 kernel (double-buffered LDS, XCD-contiguous kv heads; softmax scale folded
- * into the exponent's fma), 3 = the same kernel with the scale applied before the row max (gen-1's arithmetic: the
- * bit-exact cross-check seam between the two generations), 4 = impl 2's math with K/V staged by DMA
- * (global_load_lds_dwordx4), 5 = the counter-phase kernel: 8 waves per 256-ROW q tile, two wave groups alternating
- * matrix and softmax segments (same math per row: impl 2, 4 and 5 give bit-identical results).  Other values are
- * timing-only ablations of these kernels (tools/prefill_ablate.py). */
-/* Rows per q tile the kernel behind `impl` expects: tile_cu, total_tiles and tile_order of msgl_attn_prefill are in
- * units of this many query rows (MSGL_PREFILL_QTILE for impl 1..4, 256 for impl 5). */
+ * tiles (results do not depend on it).  impl: 0 = default = 4: K/V tiles staged global -> LDS by DMA
+ * (global_load_lds_dwordx4, ds_read_b64_tr_b16 V fragments, double-buffered LDS, XCD-contiguous kv heads, softmax scale
+ * folded into the exponent's fma); 2 = the same math with register staging (the A/B partner; bit-identical results).
+ * Every other value is refused.  (Rounds 1-3 also had 1, 3, 5 -- a first-generation and a counter-phase kernel -- and
+ * timing-only ablation codes >= 16; the former were removed, the latter exist only in a -DMSGL_PREFILL_DIAG build.) */
+/* Rows per q tile: tile_cu, total_tiles and tile_order of msgl_attn_prefill are in units of this many query rows
+ * (MSGL_PREFILL_QTILE for both kernels). */
 int msgl_attn_prefill_q_tile(int impl);
-/* diagnosis: device buffer of 32 * 8 * 256 uint64 receiving s_memtime stamps of impl 5 + 128 (NULL: off); tools/prefill_trace.py */
-int msgl_attn_prefill_trace(void* stamps);
 
 /* ------------------------------------------------------------------------
  * Sampling.  Replaces torch.argmax at P/engine/sample.py:73-74 and

@@ -24,7 +24,7 @@ BF16, FP16, F32 = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
 PREFILL_QTILE = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _u64, _sz = C.c_uint64, C.c_size_t
@@ -66,7 +66,6 @@ HIP_SIGNATURES = {
         [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _l, _l, _l, _l, _f, _i, _p, _i, _p],
     ),
     "msgl_attn_prefill_q_tile": (_i, [_i]),
-    "msgl_attn_prefill_trace": (_i, [_p]),
     "msgl_argmax_rows": (_i, [_p, _p, _l, _l, _l, _i, _p]),
     "msgl_softmax_temperature": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p]),
     "msgl_sample_top_k_top_p": (_i, [_p, _p, _p, _p, _l, _l, _l, _u64, _u64, _p]),

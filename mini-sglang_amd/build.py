@@ -55,6 +55,8 @@ COMMON_FLAGS = [
     "-I",
     str(INCLUDE),
 ]
+if os.environ.get("MSGL_PREFILL_DIAG") == "1":  # timing-only ablation variants of the prefill kernels (tools/prefill_ablate.py)
+    COMMON_FLAGS.append("-DMSGL_PREFILL_DIAG")
 
 
 def _stale(out: Path, deps: list[Path]) -> bool:

@@ -1,11 +1,16 @@
 // Paged varlen causal prefill attention for gfx950 (MFMA 32x32x16, fp32 accumulate).
 //
-// Four kernel generations with the same math per query row (impl codes in include/msgl_hip.h); the default is the
-// DMA-staged one (attn_prefill_dma_kernel).  Common to all but the last: one workgroup = 4 waves = one 128-row query
-// tile of one (request, q head); each wave owns 32 query rows.  K/V are gathered through the reference's
-// token-granular page table in 64-key tiles one tile ahead of the MFMAs: global -> registers -> LDS in the first two
-// generations, global -> LDS by DMA (global_load_lds_dwordx4) in the third; the fourth (attn_prefill_pp_kernel) runs two
-// wave groups of a 256-row tile in counter-phase (matrix segment beside softmax segment).
+// Two kernels with the same math per query row, bit-identical to each other (impl codes in include/msgl_hip.h): the
+// default DMA-staged one (attn_prefill_dma_kernel, impl 4 = 0) and its register-staged predecessor
+// (attn_prefill_tr_kernel, impl 2), kept as the A/B partner and cross-check.  One workgroup = 4 waves = one 128-row
+// query tile of one (request, q head); each wave owns 32 query rows.  K/V are gathered through the reference's
+// token-granular page table in 64-key tiles one tile ahead of the MFMAs: global -> registers -> LDS (impl 2), global ->
+// LDS by DMA (global_load_lds_dwordx4; impl 4).  Rounds 1-3 also carried a first-generation kernel (V transposed by
+// 2-byte LDS stores) and a counter-phase kernel (two wave groups of a 256-row tile, matrix segment beside softmax
+// segment: bit-identical, 43 % VALU/MFMA co-execution, NOT faster -- DESIGN.md section 8); both were removed in round 4,
+// their measurements stay under profiles/r03_prefill_*.  Ablation variants (ABL != 0: timing only, WRONG results) are
+// compiled only with -DMSGL_PREFILL_DIAG (MSGL_PREFILL_DIAG=1 python mini-sglang_amd/build.py): a stray impl code
+// cannot select one in a production build.
 //
 // Data flow per 64-key tile and wave (all in registers except the K/V tile):
 //   S^T = K . Q^T   ("swapped" QK^T: A = K rows from LDS (XOR-swizzled, conflict-free
@@ -63,7 +68,6 @@ struct PrefillParams {
   int64_t pt_stride, q_stride, kv_stride_tok, kv_stride_head, out_stride;
   int batch, hq, group;
   float scale_log2;
-  unsigned long long* trace;  // diagnosis (msgl_attn_prefill_trace, impl 5 + 128): clock stamps per wave and period, else nullptr
 };
 
 // element offset of a pool slot: slot and the token stride are both < 2^32 (checked at launch), so ONE v_mad_u64_u32
@@ -116,190 +120,6 @@ __device__ __forceinline__ TileRequest find_request(const PrefillParams& p, int 
 __device__ __forceinline__ int k_off(int key, int byte_in_row) { return key * 256 + (byte_in_row ^ ((key & 15) << 4)); }
 __device__ __forceinline__ int vt_g(int d) { return ((d >> 1) & 15) ^ ((d >> 5) & 3); }
 __device__ __forceinline__ int vt_off(int d, int unit) { return d * 128 + ((unit ^ vt_g(d)) << 3); }
-
-template <typename T>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillParams p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kKTile * kD * 2];
-  char* lds_k = lds;
-  char* lds_v = lds + kKTile * kD * 2;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int hi = lane >> 5;
-  const int hq = blockIdx.y;
-  const int kvh = hq / p.group;
-
-  // ---- which (request, q tile) is this workgroup ---------------------------------------
-  const int tile = blockIdx.x;
-  int lo = 0, hi_b = p.batch;  // find b with tile_cu[b] <= tile < tile_cu[b+1]
-  while (hi_b - lo > 1) {
-    const int mid = (lo + hi_b) >> 1;
-    if (p.tile_cu[mid] <= tile) lo = mid; else hi_b = mid;
-  }
-  const int b = lo;
-  const int q_begin = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_begin;
-  const int k_len = p.seq_lens[b];
-  const int q0 = (tile - p.tile_cu[b]) * kQTile;
-  const int row = p.req_rows ? p.req_rows[b] : b;
-  const int* pt = p.page_table + (int64_t)row * p.pt_stride;
-  const int diag = k_len - q_len;  // query j sees keys t <= diag + j
-  // keys needed by this tile: [0, kend)
-  const int kend = min(k_len, diag + min(q0 + kQTile, q_len));
-  const int ntiles = (kend + kKTile - 1) / kKTile;
-
-  // ---- Q fragments: lane owns query row (l & 31) of its wave ---------------------------
-  const int my_q = q0 + wave * 32 + (lane & 31);  // row inside the request
-  const bool q_valid = my_q < q_len;
-  const int64_t q_tok = q_begin + (q_valid ? my_q : q_len - 1);
-  U4 qf[8];
-  {
-    const uint16_t* qp = p.q + q_tok * p.q_stride + (int64_t)hq * kD + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = ldg16(qp + ks * 16);
-  }
-  const int my_qpos = diag + my_q;                  // last visible key of my row
-  const int wave_min_qpos = diag + q0 + wave * 32;  // smallest in the wave (row 0)
-
-  f32x16 o[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-  float m_run = kNegBigP, l_run = 0.f;
-
-  // ---- K/V tile staging: thread owns 16-byte pieces c = tid + 256 i, i < 4 ---------------
-  U4 kreg[4], vreg[4];
-  auto issue_loads = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int key = c >> 4, piece = c & 15;
-      const int tok = min(kt * kKTile + key, k_len - 1);  // never dereference past the sequence
-      const int64_t off = (int64_t)pt[tok] * p.kv_stride_tok + (int64_t)kvh * p.kv_stride_head + piece * 8;
-      kreg[i] = ldg16(p.k + off);
-      vreg[i] = ldg16(p.v + off);
-    }
-  };
-  auto write_lds = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i;
-      const int key = c >> 4, piece = c & 15;
-      *reinterpret_cast<U4*>(lds_k + k_off(key, piece * 16)) = kreg[i];
-      // V transposed: element (key, d) -> V^T[d][key]
-      const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int d = piece * 8 + e;
-        const uint16_t val = (uint16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-        *reinterpret_cast<uint16_t*>(lds_v + vt_off(d, key >> 2) + (key & 3) * 2) = val;
-      }
-    }
-  };
-
-  if (ntiles > 0) issue_loads(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-    write_lds();
-    __syncthreads();
-    if (kt + 1 < ntiles) issue_loads(kt + 1);  // in flight during this tile's MFMAs
-
-    const int key0 = kt * kKTile;
-    if (key0 > diag + q0 + wave * 32 + 31) continue;  // whole tile above this wave's diagonal
-
-    // ---- S^T = K . Q^T -----------------------------------------------------------------
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const int key = kb * 32 + (lane & 31);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const U4 a = *reinterpret_cast<const U4*>(lds_k + k_off(key, ks * 32 + hi * 16));
-        s[kb] = mfma32<T>(a, qf[ks], s[kb]);
-      }
-    }
-    // ---- scale, mask, online softmax (lane-local row) ------------------------------------
-    const bool need_mask = key0 + kKTile - 1 > wave_min_qpos;
-    float tmax = kNegBigP;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = s[kb][r] * p.scale_log2;
-        if (need_mask) {
-          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key > my_qpos) x = -INFINITY;
-        }
-        s[kb][r] = x;
-        tmax = fmaxf(tmax, x);
-      }
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rsum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-        s[kb][r] = e;
-        rsum += e;
-      }
-    }
-    rsum += __shfl_xor(rsum, 32, 64);
-    l_run = fmaf(l_run, alpha, rsum);
-    m_run = m_new;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
-
-    // ---- O^T += V^T . P^T ------------------------------------------------------------------
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        U4 pf;
-        pf.x = Elem<T>::pack(s[kb][8 * half + 0], s[kb][8 * half + 1]);
-        pf.y = Elem<T>::pack(s[kb][8 * half + 2], s[kb][8 * half + 3]);
-        pf.z = Elem<T>::pack(s[kb][8 * half + 4], s[kb][8 * half + 5]);
-        pf.w = Elem<T>::pack(s[kb][8 * half + 6], s[kb][8 * half + 7]);
-        const int u1 = kb * 8 + half * 4 + hi;  // 4-key unit of slots j = 0..3; j = 4..7 is unit u1 + 2
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const int d = nb * 32 + (lane & 31);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(lds_v + vt_off(d, u1));
-          const uint2 v2 = *reinterpret_cast<const uint2*>(lds_v + vt_off(d, u1 + 2));
-          U4 vf;
-          vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
-          o[nb] = mfma32<T>(vf, pf, o[nb]);
-        }
-      }
-    }
-  }
-
-  // ---- epilogue: O[q row][d] = O^T / l ---------------------------------------------------------
-  if (q_valid) {
-    const float inv = 1.0f / l_run;
-    uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = nb * 32 + 8 * rg + 4 * hi;
-        uint2 w;
-        w.x = Elem<T>::pack(o[nb][4 * rg + 0] * inv, o[nb][4 * rg + 1] * inv);
-        w.y = Elem<T>::pack(o[nb][4 * rg + 2] * inv, o[nb][4 * rg + 3] * inv);
-        *reinterpret_cast<uint2*>(op + d) = w;
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Second-generation kernel (impl 2; the default until the DMA-staged impl 4 below): same math and fragment ownership as above, but
@@ -855,360 +675,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const PrefillP
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Fourth-generation kernel (impl 5): two wave groups in counter-phase.  One workgroup = 8 waves = a 256-row query tile of
-// one (request, q head); waves w and w + 4 share a SIMD.  Every wave runs the same loop over 64-key tiles t,
-//   MATRIX segment   M(t) = [O^T += V^T(t-1) . P^T(t-1)] then [S^T(t) = K(t) . Q^T]      (32 MFMAs, LDS fragment reads)
-//   s_barrier
-//   SOFTMAX segment  S(t) = mask, row max, exp2, row sum, O rescale, pack P(t)            (VALU only)
-//   s_barrier
-// but group B (waves 4-7) passes one extra barrier before its first segment (and group A one after its last), so B runs
-// one phase behind A:
-//     phase 2t    A: M(t)      B: S(t-1)
-//     phase 2t+1  A: S(t)      B: M(t)
-// and on every SIMD one wave's MFMAs run beside the other wave's softmax arithmetic -- by construction, not by the luck
-// of how two independent workgroups drift (the 2-workgroups-per-CU kernels above co-execute VALU under only 27 % of
-// their MFMA cycles: rocprofv3 SQ_VALU_MFMA_COEXEC_CYCLES, profiles/).  Both segments cost ~1000 cycles.
-//   * rows: wave w of group g owns rows 32 (2 w + g) .. + 31 of the tile, so the causal work of the two groups is equal;
-//   * K/V tiles come by DMA (global_load_lds_dwordx4, source-side swizzle as in impl 4), every wave moving 1/8 of
-//     K(t+2) and V(t+1) at the top of its period t and waiting for them at the end of it: a period and more in flight.
-//     Three 16 KB stages each of K and V (96 KB), as six distinct LDS objects so that the compiler sees that a segment's
-//     fragment reads cannot alias the DMA writes in flight; the tile loop is unrolled by three (stage = t mod 3);
-//   * same math, fragment ownership and accumulation order per query row as impl 2/4: results are bit-identical.
-// tile_cu / total_tiles / tile_order are in units of 256-row tiles for this kernel (msgl_attn_prefill_q_tile).
-// ABL (diagnosis, wrong results): 1 = no DMA after the prologue, 2 = no QK^T MFMAs, 4 = no softmax, 8 = no PV MFMAs.
-// ------------------------------------------------------------------------------------------------
-constexpr int kPPRows = 256;
-
-template <typename T, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void attn_prefill_pp_kernel(const PrefillParams p, int total_tiles) {
-  __shared__ __attribute__((aligned(1024))) char lds[6 * kTileBytes];  // K(u) at (u mod 3) * 16 KB, V(u) at 48 KB + (u mod 3) * 16 KB
-  // The DMA destination is given to the compiler as an offset from a SECOND, unrelated LDS object: it then sees no
-  // dependence between the DMA writes and the fragment reads of `lds` and adds no s_waitcnt vmcnt of its own in front of
-  // the reads (with six tile images in flight its alias tracking of LDS DMA gives up and waits for everything, i.e. for
-  // the tiles just requested).  Every DMA -> read dependence is ordered by hand: vmcnt(0) + s_barrier below.
-  __shared__ __attribute__((aligned(16))) char dma_anchor[16];
-  uint32_t anchor_to_lds = (uint32_t)(uintptr_t)(lds_char*)lds - (uint32_t)(uintptr_t)(lds_char*)dma_anchor;
-  asm volatile("" : "+s"(anchor_to_lds));
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int grp = wave >> 2;
-  const int blk = ((wave & 3) << 1) | grp;
-
-  const int n_per = (int)(gridDim.x >> 3);
-  const int vidx = (int)(blockIdx.x & 7) * n_per + (int)(blockIdx.x >> 3);
-  if (vidx >= total_tiles * p.hq) return;
-  const int per_kv = total_tiles * p.group;
-  const int kvh = vidx / per_kv;
-  const int rem = vidx - kvh * per_kv;
-  const int ti = rem / p.group;
-  const int hq = kvh * p.group + (rem - ti * p.group);
-  const int tile = p.tile_order ? p.tile_order[ti] : ti;
-
-  const TileRequest rq = find_request(p, tile, lane);
-  const int q_begin = rq.q_begin;
-  const int q_len = rq.q_end - q_begin;
-  const int k_len = rq.k_len;
-  const int q0 = (tile - rq.tile_first) * kPPRows;
-  const int row = rq.row;
-  const int* pt = p.page_table + (int64_t)row * p.pt_stride;
-  const int diag = k_len - q_len;
-  const int kend = min(k_len, diag + min(q0 + kPPRows, q_len));
-  const int ntiles = (kend + kKTile - 1) / kKTile;  // of the workgroup (its last rows)
-
-  const int r0 = q0 + blk * 32;
-  const int my_q = r0 + (lane & 31);
-  const bool q_valid = my_q < q_len;
-  const int64_t q_tok = q_begin + (q_valid ? my_q : q_len - 1);
-  U4 qf[8];
-  {
-    const uint16_t* qp = p.q + q_tok * p.q_stride + (int64_t)hq * kD + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = ldg16(qp + ks * 16);
-  }
-  const int my_qpos = diag + my_q;
-  const int wave_min_qpos = diag + r0;
-  const int wave_max_qpos = r0 < q_len ? wave_min_qpos + 31 : -1;  // a wave with no row of the request skips every tile
-
-  f32x16 o[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-  float m_run = kNegBigP, l_run = 0.f;
-  f32x16 s[2];
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-  U4 pf[4];  // P(t) packed to 16 bit: [kb][half]
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pf[i] = U4{0u, 0u, 0u, 0u};
-
-  // ---- staging: this wave fills 1 KB chunks `wave` and `wave + 8` of a tile image (rows 4 wave .. + 3 and + 32)
-  const int st_row = 4 * wave + (lane >> 4);
-  const int64_t k_lane = (int64_t)kvh * p.kv_stride_head + (((lane & 15) ^ (st_row & 15)) << 3);
-  const int64_t v_lane = (int64_t)kvh * p.kv_stride_head + (((lane & 15) ^ ((st_row & 3) << 2)) << 3);
-  int sl[3][2];  // page-table slots of this lane's two rows: tile u in sl[u mod 3] (tiles t + 1, t + 2, t + 3 during period t)
-  auto load_slots = [&](int kt, int (&sl)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) sl[i] = pt[min(kt * kKTile + st_row + 32 * i, k_len - 1)];
-  };
-  auto dma_piece = [&](const uint16_t* base, int64_t lane_off, int slot, int img, int i) __attribute__((always_inline)) {
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + slot_offset(slot, p.kv_stride_tok) + lane_off),
-                                     (lds_void_t*)((lds_char*)dma_anchor + (anchor_to_lds + img + (wave + 8 * i) * 1024)), 16, 0, 0);
-  };
-  int koff[8], voff[4];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) koff[ks] = k_off(lane & 31, ks * 32 + hi * 16);
-  {
-    const int j = lane & 15;
-    const int r4 = j >> 2;
-    const int ch = j & 3;
-    const int w = (16 * ((lane >> 4) & 1) + 4 * ch) * 2;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) voff[nb] = hi * 1024 + r4 * 256 + (((nb ^ r4) & 3) << 6) + w;
-  }
-  constexpr int kUnitBytes = 4 * 256;
-
-  // diagnosis: s_memtime stamps of periods 8..23 of the first 32 workgroups: [wg][wave][period - 8][16]
-  unsigned long long* const trace_row = (ABL & 128) && p.trace && vidx < 32 && lane == 0 ? p.trace + ((int64_t)vidx * 8 + wave) * 256 : nullptr;
-  auto stamp = [&](int kt, int k) __attribute__((always_inline)) {
-    if constexpr (ABL & 128) {
-      if (trace_row && kt >= 8 && kt < 24) trace_row[(kt - 8) * 16 + k] = __builtin_readcyclecounter();
-    }
-  };
-
-  U4 vfp[4];  // V^T fragments of the first four P.V MFMAs of the NEXT matrix segment, read at the end of a softmax segment
-#pragma unroll
-  for (int i = 0; i < 4; ++i) vfp[i] = U4{0u, 0u, 0u, 0u};
-  auto read_vf = [&](const char* vimg, int j) __attribute__((always_inline)) {  // MFMA j of P.V: keys 32 (j >> 3) + 16 ((j >> 2) & 1) .., d block j & 3
-    const int ub = ((j >> 3) * 8 + ((j >> 2) & 1) * 4) * kUnitBytes;
-    const uint2 v1 = tr_read_b64(vimg + voff[j & 3] + ub);
-    const uint2 v2 = tr_read_b64(vimg + voff[j & 3] + ub + 2 * kUnitBytes);
-    U4 vf;
-    vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
-    return vf;
-  };
-  // ---- matrix segment of tile t: P.V of tile t - 1 (image vimg), then QK^T of tile t (image kimg).  Issue order pinned
-  //      (sched_barrier): every LDS read is issued 4 MFMAs ahead of the MFMA that consumes it; the first K fragments are
-  //      requested before P.V starts
-  auto seg_matrix = [&](const char* kimg, const char* vimg, const int kt) __attribute__((always_inline)) {
-    const bool do_pv = kt >= 1 && (kt - 1) * kKTile <= wave_max_qpos;
-    const bool do_qk = kt < ntiles && kt * kKTile <= wave_max_qpos;
-    auto read_kf = [&](int i) __attribute__((always_inline)) {
-      return *reinterpret_cast<const U4*>(kimg + koff[i & 7] + (i >> 3) * 8192);
-    };
-    constexpr auto qk_idx = [](int i) { return (i & 1) * 8 + (i >> 1); };  // MFMA i of QK^T: key block i & 1, k-step i >> 1
-    U4 kf[16];
-    if (do_qk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) kf[qk_idx(i)] = read_kf(qk_idx(i));
-    }
-    stamp(kt, 5);
-    if (do_pv) {
-      U4 vf[16];
-      if (grp == 1) {  // requested at the end of this wave's last softmax segment
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vf[j] = vfp[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vf[j] = read_vf(vimg, j);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if constexpr (!(ABL & 8)) o[j & 3] = mfma32<T>(vf[j], pf[j >> 2], o[j & 3]);
-        if (j + 4 < 16) vf[j + 4] = read_vf(vimg, j + 4);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    stamp(kt, 6);
-    if (do_qk) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {  // the two key blocks' accumulation chains alternate
-        if constexpr (!(ABL & 2)) s[i & 1] = mfma32<T>(kf[qk_idx(i)], qf[i >> 1], s[i & 1]);
-        if (i + 4 < 16) kf[qk_idx(i + 4)] = read_kf(qk_idx(i + 4));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-
-  // ---- softmax segment of tile t: s (scores) -> pf (probabilities, 16 bit), running max / sum, O rescale.  Carries this
-  //      wave's DMA pieces of K(t+2) -> kdst and V(t+1) -> vdst between its blocks (a VMEM issue among VALU work costs
-  //      least: issued back to back at the top of the matrix segment the eight waves' pieces held the MFMAs up for
-  //      ~1300 cycles per period, tools/prefill_trace.py), and (group B) ends by requesting the first V^T fragments of
-  //      the next matrix segment from V(t) (vnext)
-  auto seg_softmax = [&](auto RC, const int kt, int kdst, int vdst, const char* vnext) __attribute__((always_inline)) {
-    constexpr int R = decltype(RC)::value;
-    const bool act = kt < ntiles && kt * kKTile <= wave_max_qpos;
-    const bool dk = !(ABL & 1) && kt + 2 < ntiles, dv = !(ABL & 1) && kt + 1 < ntiles;
-    float m_new = m_run, alpha = 1.f, rsum = 0.f;
-    if (act && !(ABL & 4)) {
-      const int key0 = kt * kKTile;
-      if (key0 + kKTile - 1 > wave_min_qpos) {  // the tile crosses this wave's diagonal: key0 + c + 4 hi > my_qpos <=> c > thr
-        const int thr = my_qpos - key0 - 4 * hi;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (kb * 32 + (r & 3) + 8 * (r >> 2) > thr) s[kb][r] = -INFINITY;
-      }
-      float tmax = kNegBigP;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * p.scale_log2;
-      m_new = fmaxf(m_run, tmax);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    }
-    stamp(kt, 8);
-    if (dk) dma_piece(p.k, k_lane, sl[(R + 2) % 3][0], kdst, 0);
-    stamp(kt, 9);
-    if (act && !(ABL & 4)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(s[0][r], p.scale_log2, -m_new));
-        s[0][r] = e;
-        rsum += e;
-      }
-    }
-    stamp(kt, 10);
-    if (dk) dma_piece(p.k, k_lane, sl[(R + 2) % 3][1], kdst, 1);
-    stamp(kt, 11);
-    if (act && !(ABL & 4)) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(s[1][r], p.scale_log2, -m_new));
-        s[1][r] = e;
-        rsum += e;
-      }
-    }
-    stamp(kt, 12);
-    if (dv) dma_piece(p.v, v_lane, sl[(R + 1) % 3][0], vdst, 0);
-    stamp(kt, 13);
-    if (act) {
-      if constexpr (ABL & 4) {
-        l_run += s[0][0] + s[1][15];
-        m_run = 0.f;
-      } else {
-        rsum += __shfl_xor(rsum, 32, 64);
-        l_run = fmaf(l_run, alpha, rsum);
-        if (!__all(m_new == m_run)) {
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[nb][r] *= alpha;
-        }
-        m_run = m_new;
-      }
-    }
-    stamp(kt, 14);
-    if (dv) dma_piece(p.v, v_lane, sl[(R + 1) % 3][1], vdst, 1);
-    stamp(kt, 15);
-    if (!(ABL & 1) && kt + 3 < ntiles) load_slots(kt + 3, sl[R]);  // its old content (tile t) is dead
-    if (act) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          U4 w;
-          w.x = Elem<T>::pack(s[kb][8 * half + 0], s[kb][8 * half + 1]);
-          w.y = Elem<T>::pack(s[kb][8 * half + 2], s[kb][8 * half + 3]);
-          w.z = Elem<T>::pack(s[kb][8 * half + 4], s[kb][8 * half + 5]);
-          w.w = Elem<T>::pack(s[kb][8 * half + 6], s[kb][8 * half + 7]);
-          pf[kb * 2 + half] = w;
-        }
-      // group B only: in group A's softmax segment (one phase earlier) group B's pieces of V(t) may still be in flight
-      if (grp == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vfp[j] = read_vf(vnext, j);
-      }
-    }
-  };
-
-  // one period of tile t; R = t mod 3: K(u) lives in k[u mod 3], V(u) in v[u mod 3]
-  auto period = [&](auto RC, const int kt) __attribute__((always_inline)) {
-    constexpr int R = decltype(RC)::value;
-    constexpr int kimg[3] = {0, kTileBytes, 2 * kTileBytes};
-    constexpr int vimg[3] = {3 * kTileBytes, 4 * kTileBytes, 5 * kTileBytes};
-    stamp(kt, 0);
-    if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(0);
-    if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(1);
-    seg_matrix(lds + kimg[R], lds + vimg[(R + 2) % 3], kt);
-    stamp(kt, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the pieces of K(t+1), V(t) this wave sent off in its last softmax segment have landed
-    stamp(kt, 7);
-    asm volatile("s_barrier" ::: "memory");
-    stamp(kt, 2);
-    if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(1);
-    if constexpr (ABL & 32) __builtin_amdgcn_s_setprio(0);
-    seg_softmax(RC, kt, kimg[(R + 2) % 3], vimg[(R + 1) % 3], lds + vimg[R]);
-    stamp(kt, 3);
-    asm volatile("s_barrier" ::: "memory");
-  };
-
-  if (ntiles > 0) {
-    // prologue: K(0), V(0), K(1) with the slots of tiles 0 and 1; slots of tile 2
-    load_slots(0, sl[0]);
-    load_slots(ntiles > 1 ? 1 : 0, sl[1]);
-    load_slots(ntiles > 2 ? 2 : 0, sl[2]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      dma_piece(p.k, k_lane, sl[0][i], 0, i);
-      dma_piece(p.v, v_lane, sl[0][i], 3 * kTileBytes, i);
-      if (ntiles > 1) dma_piece(p.k, k_lane, sl[1][i], kTileBytes, i);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("s_barrier" ::: "memory");
-    if constexpr (ABL & 64) { if (grp == 1) __builtin_amdgcn_s_setprio(1); }
-    if (grp == 1) asm volatile("s_barrier" ::: "memory");  // group B: one phase behind
-    for (int kt = 0; kt <= ntiles; kt += 3) {  // periods 0 .. ntiles (the last one only finishes P.V of the last tile)
-      period(std::integral_constant<int, 0>{}, kt);
-      if (kt + 1 <= ntiles) period(std::integral_constant<int, 1>{}, kt + 1);
-      if (kt + 2 <= ntiles) period(std::integral_constant<int, 2>{}, kt + 2);
-    }
-    if (grp == 0) asm volatile("s_barrier" ::: "memory");
-  }
-
-  if (q_valid) {
-    const float inv = 1.0f / l_run;
-    uint16_t* op = p.out + (int64_t)(q_begin + my_q) * p.out_stride + (int64_t)hq * kD;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = nb * 32 + 8 * rg + 4 * hi;
-        uint2 w;
-        w.x = Elem<T>::pack(o[nb][4 * rg + 0] * inv, o[nb][4 * rg + 1] * inv);
-        w.y = Elem<T>::pack(o[nb][4 * rg + 2] * inv, o[nb][4 * rg + 3] * inv);
-        *reinterpret_cast<uint2*>(op + d) = w;
-      }
-    }
-  }
-}
-
 }  // namespace msgl
 
 using namespace msgl;
 
-static unsigned long long* g_prefill_trace = nullptr;
-// diagnosis: device buffer of 32 * 8 * 256 uint64 for the clock stamps of impl 5 + 128 (nullptr: off)
-extern "C" int msgl_attn_prefill_trace(void* stamps) {
-  g_prefill_trace = static_cast<unsigned long long*>(stamps);
-  return MSGL_OK;
-}
-
-extern "C" int msgl_attn_prefill_q_tile(int impl) { return (impl == 5 || (impl >= 128 && impl < 512)) ? kPPRows : kQTile; }
+extern "C" int msgl_attn_prefill_q_tile(int /*impl*/) { return kQTile; }
 
 extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, const void* v_cache,
                                  const int32_t* page_table, int64_t pt_stride, const int32_t* req_rows,
@@ -1218,8 +689,14 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
                                  int64_t out_stride_tok, float sm_scale, int dtype, const int32_t* tile_order,
                                  int impl, void* stream) {
   MSGL_REQUIRE(batch >= 0 && total_tiles >= 0, "attn_prefill: negative sizes");
-  MSGL_REQUIRE((impl >= 0 && impl <= 5) || (impl >= 16 && impl <= 48) || (impl >= 64 && impl < 512),
-               "attn_prefill: impl %d (0 default, 1 register-transposed V, 2 tr-read, 3 tr-read unfolded scale, 16 + bits: ablations)", impl);
+#ifdef MSGL_PREFILL_DIAG
+  MSGL_REQUIRE(impl == 0 || impl == 2 || impl == 4 || (impl >= 16 && impl < 48) || (impl >= 64 && impl < 128),
+               "attn_prefill: impl %d (0 = 4 DMA-staged, 2 register-staged; diagnostic build: 16 + bits / 64 + bits = ablations)", impl);
+#else
+  MSGL_REQUIRE(impl == 0 || impl == 2 || impl == 4,
+               "attn_prefill: impl %d (0 = 4 the DMA-staged kernel, 2 the register-staged kernel; ablation codes need a "
+               "-DMSGL_PREFILL_DIAG build)", impl);
+#endif
   if (batch == 0 || total_tiles == 0) return MSGL_OK;
   MSGL_REQUIRE(out && q && k_cache && v_cache && page_table && seq_lens && cu_seqlens_q && tile_cu,
                "attn_prefill: null pointer");
@@ -1253,61 +730,43 @@ extern "C" int msgl_attn_prefill(void* out, const void* q, const void* k_cache, 
   p.hq = num_q_heads;
   p.group = num_q_heads / num_kv_heads;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
-  p.trace = g_prefill_trace;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype != MSGL_BF16 && dtype != MSGL_FP16) {
     set_error("attn_prefill: unsupported dtype code %d", dtype);
     return MSGL_EINVAL;
   }
-  if (impl == 0) impl = 4;  // the DMA-staged kernel; impl 1, 2, 3 keep the earlier generations callable (cross-checks in tests)
-  if (impl == 1) {  // first-generation kernel: 2-D grid in natural order (tile_order unused)
-    const dim3 grid((unsigned)total_tiles, (unsigned)num_q_heads), block(256);
-    if (dtype == MSGL_BF16) attn_prefill_kernel<BF16><<<grid, block, 0, s>>>(p);
-    else attn_prefill_kernel<FP16><<<grid, block, 0, s>>>(p);
-  } else {
-    const int64_t total = (int64_t)total_tiles * num_q_heads;
-    MSGL_REQUIRE(total < (1ll << 30), "attn_prefill: %lld workgroups", (long long)total);
-    const unsigned blocks = (unsigned)((total + 7) / 8) * 8;  // 8 XCDs x n_per
-    if (impl == 5 || (impl >= 128 && impl < 512)) {  // counter-phase kernel (256-row tiles); 128 + bits: its ablations
-      const int abl = impl == 5 ? 0 : impl - 128;
-      MSGL_REQUIRE(abl == 0 || dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
-#define MSGL_PF_PP(A) case A: attn_prefill_pp_kernel<BF16, A><<<dim3(blocks), dim3(512), 0, s>>>(p, total_tiles); break
-      if (dtype == MSGL_FP16) attn_prefill_pp_kernel<FP16><<<dim3(blocks), dim3(512), 0, s>>>(p, total_tiles);
-      else switch (abl) {
-        MSGL_PF_PP(0); MSGL_PF_PP(1); MSGL_PF_PP(2); MSGL_PF_PP(4); MSGL_PF_PP(8); MSGL_PF_PP(10); MSGL_PF_PP(14); MSGL_PF_PP(15); MSGL_PF_PP(11); MSGL_PF_PP(5); MSGL_PF_PP(16); MSGL_PF_PP(32); MSGL_PF_PP(64); MSGL_PF_PP(128); MSGL_PF_PP(129); MSGL_PF_PP(132); MSGL_PF_PP(136); MSGL_PF_PP(138);
-        default: set_error("attn_prefill: unknown ablation %d", abl); return MSGL_EINVAL;
-      }
-#undef MSGL_PF_PP
-    } else if (impl == 4 || (impl >= 64 && impl < 128)) {  // DMA-staged kernel; 64 + bits: its ablations
-      const int abl = impl == 4 ? 0 : impl - 64;
-      MSGL_REQUIRE(abl == 0 || dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
-#define MSGL_PF_DMA(A) case A: attn_prefill_dma_kernel<BF16, A><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles); break
-      if (dtype == MSGL_FP16) attn_prefill_dma_kernel<FP16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
-      else switch (abl) {
-        MSGL_PF_DMA(0); MSGL_PF_DMA(1); MSGL_PF_DMA(2); MSGL_PF_DMA(4); MSGL_PF_DMA(8); MSGL_PF_DMA(6); MSGL_PF_DMA(12);
-        MSGL_PF_DMA(10); MSGL_PF_DMA(14); MSGL_PF_DMA(15); MSGL_PF_DMA(16); MSGL_PF_DMA(32);
-        default: set_error("attn_prefill: unknown ablation %d", abl); return MSGL_EINVAL;
-      }
-#undef MSGL_PF_DMA
-    } else if (impl == 48) {  // diagnosis: the default kernel at ONE workgroup per CU (40 KB of unused dynamic LDS on top of its 64)
-      MSGL_REQUIRE(dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_tr_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 40 << 10);
-      attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 40 << 10, s>>>(p, total_tiles);
-    } else if (impl >= 16 && impl < 48) {  // diagnosis: ablation bits = impl - 16
-#define MSGL_PF_ABL(A) case A: attn_prefill_tr_kernel<BF16, true, A><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles); break
-      MSGL_REQUIRE(dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
-      switch (impl - 16) {
-        MSGL_PF_ABL(1); MSGL_PF_ABL(2); MSGL_PF_ABL(4); MSGL_PF_ABL(8); MSGL_PF_ABL(6); MSGL_PF_ABL(10); MSGL_PF_ABL(12);
-        MSGL_PF_ABL(14); MSGL_PF_ABL(15); MSGL_PF_ABL(17); MSGL_PF_ABL(31); MSGL_PF_ABL(16);
-        default: set_error("attn_prefill: unknown ablation %d", impl - 16); return MSGL_EINVAL;
-      }
-#undef MSGL_PF_ABL
-    } else if (impl == 3) {
-      if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16, false><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
-      else attn_prefill_tr_kernel<FP16, false><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
-    } else if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+  if (impl == 0) impl = 4;  // the DMA-staged kernel; impl 2 keeps its predecessor callable (A/B timing, cross-check in tests)
+  const int64_t total = (int64_t)total_tiles * num_q_heads;
+  MSGL_REQUIRE(total < (1ll << 30), "attn_prefill: %lld workgroups", (long long)total);
+  const unsigned blocks = (unsigned)((total + 7) / 8) * 8;  // 8 XCDs x n_per
+  if (impl == 4) {
+    if (dtype == MSGL_BF16) attn_prefill_dma_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+    else attn_prefill_dma_kernel<FP16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
+  } else if (impl == 2) {
+    if (dtype == MSGL_BF16) attn_prefill_tr_kernel<BF16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
     else attn_prefill_tr_kernel<FP16><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles);
   }
+#ifdef MSGL_PREFILL_DIAG
+  else if (impl >= 64) {  // DMA-staged kernel, ablation bits = impl - 64 (timing only: WRONG results)
+    MSGL_REQUIRE(dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
+#define MSGL_PF_DMA(A) case A: attn_prefill_dma_kernel<BF16, A><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles); break
+    switch (impl - 64) {
+      MSGL_PF_DMA(1); MSGL_PF_DMA(2); MSGL_PF_DMA(4); MSGL_PF_DMA(8); MSGL_PF_DMA(6); MSGL_PF_DMA(12);
+      MSGL_PF_DMA(10); MSGL_PF_DMA(14); MSGL_PF_DMA(15); MSGL_PF_DMA(16); MSGL_PF_DMA(32);
+      default: set_error("attn_prefill: unknown ablation %d", impl - 64); return MSGL_EINVAL;
+    }
+#undef MSGL_PF_DMA
+  } else {  // register-staged kernel, ablation bits = impl - 16
+    MSGL_REQUIRE(dtype == MSGL_BF16, "attn_prefill: ablations are bf16 only");
+#define MSGL_PF_ABL(A) case A: attn_prefill_tr_kernel<BF16, true, A><<<dim3(blocks), dim3(256), 0, s>>>(p, total_tiles); break
+    switch (impl - 16) {
+      MSGL_PF_ABL(1); MSGL_PF_ABL(2); MSGL_PF_ABL(4); MSGL_PF_ABL(8); MSGL_PF_ABL(6); MSGL_PF_ABL(10); MSGL_PF_ABL(12);
+      MSGL_PF_ABL(14); MSGL_PF_ABL(15); MSGL_PF_ABL(17); MSGL_PF_ABL(31); MSGL_PF_ABL(16);
+      default: set_error("attn_prefill: unknown ablation %d", impl - 16); return MSGL_EINVAL;
+    }
+#undef MSGL_PF_ABL
+  }
+#endif
   MSGL_CHECK_LAUNCH("attn_prefill");
   return MSGL_OK;
 }

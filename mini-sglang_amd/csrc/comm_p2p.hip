@@ -72,7 +72,16 @@ __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int
     while (!bad &&
            __hip_atomic_load(&self->flag[b][phase][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > spin_limit) {
+      ++spins;
+      // a peer that gave up writes ITS verdict into every rank's header (below): a live rank stops waiting for flags that
+      // will never come and poisons with it, instead of passing the barrier later and summing staging areas the failed
+      // rank has meanwhile overwritten
+      if ((spins & 1023u) == 0 &&
+          __hip_atomic_load(&self->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        s_bad = 1;
+        break;
+      }
+      if (spins > spin_limit) {
         __hip_atomic_store(&self->error, 1u + (uint32_t)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         s_bad = 1;
         break;
@@ -81,6 +90,12 @@ __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int
   }
   __syncthreads();
   const bool out = s_bad != 0;
+  if (out && !bad && threadIdx.x < world && (int)threadIdx.x != rank) {
+    // first block of this rank to see the failure: tell every peer (sticky there as here; their kernels poison from
+    // their next barrier / next launch on, and their hosts raise at the next poll)
+    P2PHeader* peer = reinterpret_cast<P2PHeader*>(peers.base[threadIdx.x]);
+    __hip_atomic_store(&peer->error, 1u + (uint32_t)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (threadIdx.x == 0) self->seq[b][phase] = seq;
   return out;
 }

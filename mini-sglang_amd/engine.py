@@ -19,7 +19,7 @@ from . import flashinfer_compat as fi
 from . import ops
 from .attention import HipAttnBackend
 from .core import Batch, Context, Req, SamplingParams, set_global_ctx
-from .kvcache import create_kvcache_pool, div_even
+from .kvcache import create_kvcache_pool, heads_per_rank
 from .model import Communicator, DenseDecoder, ModelConfig
 
 
@@ -115,7 +115,7 @@ def _align_up_32(n: int) -> int:
 def determine_num_pages(free_before: int, free_after: int, cfg: EngineConfig) -> int:
     """P/engine/engine.py:148-168: (memory_ratio * free_before - model_bytes) // bytes_per_page."""
     m = cfg.model
-    cache_per_page = (2 * m.head_dim * div_even(m.num_kv_heads, cfg.tp_size, allow_replicate=True) * cfg.page_size
+    cache_per_page = (2 * m.head_dim * heads_per_rank(m.num_kv_heads, cfg.tp_size, replicate=True) * cfg.page_size
                       * torch.empty((), dtype=cfg.dtype).element_size() * m.num_layers)
     if cfg.num_page_override is not None:
         return cfg.num_page_override
@@ -173,13 +173,23 @@ class GraphRunner:
         batch.padded_reqs = batch.reqs
         backend.prepare_for_capture(batch)
         batch.input_ids, batch.out_loc, batch.positions = self.input_ids[:bs], self.out_loc[:bs], self.positions[:bs]
+        static = self.logits[:bs]
+
+        def forward_into_static() -> None:
+            # the model writes the LM head straight into the static buffer where it can (tp = 1); whatever else it
+            # returns is copied there INSIDE the graph, as the reference does (P/engine/graph.py:139-141) -- a replay
+            # must never hand back a buffer the captured kernels did not write
+            out = engine.model.forward(engine.ctx, batch, logits_out=static)
+            if out.data_ptr() != static.data_ptr() or out.shape != static.shape or out.stride() != static.stride():
+                static.copy_(out)
+
         with engine.ctx.forward_batch(batch):
-            engine.model.forward(engine.ctx, batch, logits_out=self.logits[:bs])
+            forward_into_static()
             # with a communicator inside the graph, RCCL's proxy thread may touch the HIP API while this
             # thread captures: only this thread's calls are held to the capture rules then
             mode = "thread_local" if engine.cfg.tp_size > 1 else "global"
             with torch.cuda.graph(graph, pool=self._pool, stream=engine.stream, capture_error_mode=mode):
-                engine.model.forward(engine.ctx, batch, logits_out=self.logits[:bs])
+                forward_into_static()
         if self._pool is None:
             self._pool = graph.pool()
         self.graph_map[bs] = graph

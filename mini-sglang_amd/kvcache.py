@@ -1,11 +1,12 @@
-"""KV pool mirror of MHAKVCache (P/kvcache/mha_pool.py:10-68, interface P/kvcache/base.py:10-37).
+"""KV pool behind the reference's KV-cache interface (P/kvcache/base.py:10-37; the pool it replaces: P/kvcache/mha_pool.py:10-68).
 
-Layout in HBM (one allocation for the process lifetime, sized for 288 GB parts):
-    [2 (k|v), num_layers, num_pages, page_size, local_kv_heads, head_dim]
-so one layer's K (or V) is a contiguous [num_pages * page_size, local_kv_heads * head_dim] slab
-of token rows: a token's row is local_kv_heads x 256 B contiguous (2048 B at TP1 ... 256 B at
-TP8), slots are token-granular indices into that slab, and the extra last page is the dummy
-target of padded graph rows (P/engine/engine.py:57-63, 89-98).
+One HBM allocation for the process lifetime, sized for 288 GB parts:
+    pool[2 (k|v), num_layers, num_pages, page_size, local_kv_heads, head_dim]
+One layer's K (or V) is therefore a contiguous slab of token rows, a token's row is local_kv_heads x 256 B
+(2048 B at TP1 ... 256 B at TP8), slots are token-granular indices into that slab, and the extra last page is
+the dummy target of padded graph rows (P/engine/engine.py:57-63, 89-98).  Only the stand-alone driver of this
+repository (engine.py) builds this class; behind the plugin the reference's own MHAKVCache object is used and
+its `store_kv` is what gets rebound.
 """
 from __future__ import annotations
 
@@ -14,46 +15,48 @@ import torch
 from . import ops
 
 
-def div_even(a: int, b: int, allow_replicate: bool = False) -> int:
-    """P/utils/misc.py:20-26."""
-    if allow_replicate and b > a:
-        assert b % a == 0, f"{b = } must be divisible by {a = } for KV head replication"
+def heads_per_rank(total: int, ranks: int, replicate: bool = False) -> int:
+    """How many of `total` heads (or MLP columns) one of `ranks` tensor-parallel ranks owns.  With replicate=True a
+    group larger than the head count keeps one head per rank, shared by ranks // total neighbours (KV heads at
+    tp > Hkv).  Same arithmetic as the reference's sharding helper (P/utils/misc.py:20-26)."""
+    if replicate and ranks > total:
+        if ranks % total:
+            raise ValueError(f"cannot replicate {total} heads over {ranks} ranks (not a multiple)")
         return 1
-    assert a % b == 0, f"{a = } must be divisible by {b = }"
-    return a // b
+    if total % ranks:
+        raise ValueError(f"cannot split {total} evenly over {ranks} ranks")
+    return total // ranks
 
 
 class MHAKVCache:
     def __init__(self, num_kv_heads: int, num_layers: int, head_dim: int, num_pages: int, page_size: int,
                  dtype: torch.dtype, device: torch.device, tp_size: int = 1) -> None:
-        local_kv_heads = div_even(num_kv_heads, tp_size, allow_replicate=True)
-        self._kv_buffer = torch.empty((2, num_layers, num_pages, page_size, local_kv_heads, head_dim),
-                                      device=device, dtype=dtype)
-        self._num_layers = num_layers
-        self._k_buffer = self._kv_buffer[0]
-        self._v_buffer = self._kv_buffer[1]
-        self._device = device
-        self._storage_shape = (num_pages * page_size, local_kv_heads, head_dim)
-        self._row_shape = (num_pages * page_size, local_kv_heads * head_dim)
+        heads = heads_per_rank(num_kv_heads, tp_size, replicate=True)
+        slots = num_pages * page_size
+        self.pool = torch.empty((2, num_layers, num_pages, page_size, heads, head_dim), device=device, dtype=dtype)
+        self._layers = num_layers
+        self._tok_shape = (slots, heads, head_dim)   # [slot, head, dim] view of one layer
+        self._row_shape = (slots, heads * head_dim)  # [slot, row] view of one layer
 
+    # the reference's accessors ([num_pages, page_size, heads, dim] per layer)
     def k_cache(self, index: int) -> torch.Tensor:
-        return self._k_buffer[index]
+        return self.pool[0, index]
 
     def v_cache(self, index: int) -> torch.Tensor:
-        return self._v_buffer[index]
+        return self.pool[1, index]
 
     # token-row views used by the kernels
     def k_rows(self, index: int) -> torch.Tensor:
-        return self._k_buffer[index].view(self._row_shape)
+        return self.pool[0, index].view(self._row_shape)
 
     def v_rows(self, index: int) -> torch.Tensor:
-        return self._v_buffer[index].view(self._row_shape)
+        return self.pool[1, index].view(self._row_shape)
 
     def k_tokens(self, index: int) -> torch.Tensor:
-        return self._k_buffer[index].view(self._storage_shape)
+        return self.pool[0, index].view(self._tok_shape)
 
     def v_tokens(self, index: int) -> torch.Tensor:
-        return self._v_buffer[index].view(self._storage_shape)
+        return self.pool[1, index].view(self._tok_shape)
 
     def store_kv(self, k: torch.Tensor, v: torch.Tensor, out_loc: torch.Tensor, layer_id: int) -> None:
         ops.store_kv(self.k_rows(layer_id), self.v_rows(layer_id), out_loc,
@@ -61,15 +64,15 @@ class MHAKVCache:
 
     @property
     def device(self) -> torch.device:
-        return self._device
+        return self.pool.device
 
     @property
     def dtype(self) -> torch.dtype:
-        return self._kv_buffer.dtype
+        return self.pool.dtype
 
     @property
     def num_layers(self) -> int:
-        return self._num_layers
+        return self._layers
 
 
 def create_kvcache_pool(model_config, num_pages: int, page_size: int, dtype: torch.dtype, device: torch.device,

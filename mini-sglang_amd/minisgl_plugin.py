@@ -248,9 +248,25 @@ def _install_fused_gated_mlp() -> None:
     reference_forward = GatedMLP.forward
 
     def forward(self, x):
-        if getattr(self, "_msgl_gate_up_ilv", False) and x.is_cuda and x.dim() == 2 and x.stride(1) == 1:
-            return self.down_proj.forward(ops.linear_silu(x, self.gate_up_proj.weight))
-        return reference_forward(self, x)
+        if not getattr(self, "_msgl_gate_up_ilv", False):
+            return reference_forward(self, x)
+        # the weight rows ARE permuted: the reference forward (contiguous [gate | up] halves) would be silently wrong on
+        # them, so every input either takes the interleaved path or is refused
+        w = self.gate_up_proj.weight
+        if w.data_ptr() != getattr(self, "_msgl_gate_up_ptr", None):
+            # load_state_dict (P/layers/base.py:31-49) REPLACES the tensor: the new one holds the reference's [gate; up]
+            # rows, the permuted storage is gone -- this layer is a plain reference layer again until the next capture
+            # converts it (an IN-PLACE rewrite cannot be seen from here: restore_gate_up_layout() first, see its docstring)
+            self._msgl_gate_up_ilv, self._msgl_gate_up_ptr = False, None
+            return reference_forward(self, x)
+        if not x.is_cuda:
+            raise RuntimeError("GatedMLP with interleaved gate_up rows runs on the HIP device only (no CPU fallback)")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        y = self.down_proj.forward(ops.linear_silu(x2, w))
+        return y if x.dim() == 2 else y.view(*lead, y.shape[-1])
 
     forward._msgl_fused = True  # type: ignore[attr-defined]
     forward._msgl_reference = reference_forward  # type: ignore[attr-defined]
@@ -285,7 +301,52 @@ def _interleave_gated_mlps(model: Any) -> int:
                 w = gu.weight.data if hasattr(gu.weight, "data") else gu.weight
                 w.copy_(ops.interleave_gate_up(w))
                 op._msgl_gate_up_ilv = True
+                op._msgl_gate_up_ptr = gu.weight.data_ptr()  # the storage that holds permuted rows (checked per forward)
                 done += 1
+            return
+        if isinstance(op, BaseOP):
+            for sub in vars(op).values():
+                for s_ in (sub if isinstance(sub, (list, tuple)) else (sub,)):
+                    if isinstance(s_, BaseOP):
+                        walk(s_)
+
+    walk(model)
+    return done
+
+
+def gate_up_reference(op: Any) -> Any:
+    """gate_up_proj.weight of a GatedMLP in the REFERENCE's row order [gate; up] (P/layers/linear.py:50-62), whatever
+    order the storage is in: what a state_dict export or a comparison against a checkpoint must read."""
+    import torch
+
+    from . import ops
+
+    w = op.gate_up_proj.weight
+    if not getattr(op, "_msgl_gate_up_ilv", False):
+        return w
+    idx = ops.gate_up_interleave_index(w.shape[0] // 2, w.device)
+    inv = torch.empty_like(idx)
+    inv[idx] = torch.arange(idx.numel(), device=w.device)
+    return w.index_select(0, inv)
+
+
+def restore_gate_up_layout(model: Any) -> int:
+    """Undo `_interleave_gated_mlps` in place (rows back to [gate; up], flag cleared) on every converted GatedMLP:
+    call before anything rewrites or exports the weights (load_state_dict, a reload, state_dict); the next graph
+    capture converts them again.  Returns the number of layers restored."""
+    from minisgl.layers.base import BaseOP
+
+    done = 0
+
+    def walk(op: Any) -> None:
+        nonlocal done
+        if getattr(op, "_msgl_gate_up_ilv", False):
+            w = op.gate_up_proj.weight
+            if w.data_ptr() == getattr(op, "_msgl_gate_up_ptr", None):  # else: already replaced by un-permuted rows
+                (w.data if hasattr(w, "data") else w).copy_(gate_up_reference(op))
+            op._msgl_gate_up_ilv = False
+            op._msgl_gate_up_ptr = None
+            done += 1
             return
         if isinstance(op, BaseOP):
             for sub in vars(op).values():

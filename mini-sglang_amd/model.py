@@ -24,7 +24,7 @@ import torch
 
 from . import flashinfer_compat as fi
 from . import ops
-from .kvcache import div_even
+from .kvcache import heads_per_rank
 
 # MSGL_DISABLE_SLAB_NORM=1: keep the split-K reduce of o_proj / down_proj as its own launch (A/B switch)
 _SLAB_NORM = os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1"
@@ -152,9 +152,9 @@ class DenseDecoder:
         self.comm_overlap = comm_overlap
         self.side_stream = torch.cuda.Stream(device=device) if (self.comm_split_tokens and comm_overlap) else None
         D = cfg.head_dim
-        self.hq = div_even(cfg.num_qo_heads, tp_size)
-        self.hkv = div_even(cfg.num_kv_heads, tp_size, allow_replicate=True)
-        self.inter = div_even(cfg.intermediate_size, tp_size)
+        self.hq = heads_per_rank(cfg.num_qo_heads, tp_size)
+        self.hkv = heads_per_rank(cfg.num_kv_heads, tp_size, replicate=True)
+        self.inter = heads_per_rank(cfg.intermediate_size, tp_size)
         self.vocab_tp, self.vocab_range = vocab_shard(cfg.vocab_size, tp_size, tp_rank)
         self.q_dim, self.kv_dim = self.hq * D, self.hkv * D
 

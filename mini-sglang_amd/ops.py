@@ -357,6 +357,9 @@ def attn_decode_select(impl: int) -> None:
 
 
 PREFILL_IMPL = int(os.environ.get("MSGL_PREFILL_IMPL", "0"))  # 0 = the library's default kernel (include/msgl_hip.h)
+if PREFILL_IMPL not in (0, 2, 4):
+    raise ValueError(f"MSGL_PREFILL_IMPL={PREFILL_IMPL}: 0 / 4 (DMA-staged, the default) or 2 (register-staged A/B partner); the "
+                     "timing-only ablation codes exist in a diagnostic build only and are passed as impl= by tools/prefill_ablate.py")
 
 
 def prefill_q_tile(impl: Optional[int] = None) -> int:
@@ -370,9 +373,8 @@ def attn_prefill(out: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, v_ca
                  cu_seqlens_q: torch.Tensor, tile_cu: torch.Tensor, batch: int, total_tiles: int,
                  sm_scale: float, tile_order: Optional[torch.Tensor] = None, impl: Optional[int] = None) -> None:
     """tile_order: optional int32 [total_tiles] schedule of the q tiles (heaviest first); impl: None = process default
-    (PREFILL_IMPL), 0 library default, 1 first-generation kernel, 2 tr-read kernel, 3 tr-read kernel with gen-1's softmax
-    arithmetic, 4 DMA-staged, 5 counter-phase kernel (include/msgl_hip.h).  tile_cu / total_tiles / tile_order are in
-    units of prefill_q_tile(impl) query rows."""
+    (PREFILL_IMPL), 0 = 4 the DMA-staged kernel, 2 its register-staged predecessor (include/msgl_hip.h; anything else is
+    refused by the library).  tile_cu / total_tiles / tile_order are in units of prefill_q_tile(impl) query rows."""
     _need_cuda(out, q, k_cache, v_cache, page_table, seq_lens, cu_seqlens_q, tile_cu)
     if impl is None:
         impl = PREFILL_IMPL

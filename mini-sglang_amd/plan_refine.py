@@ -7,7 +7,10 @@ state, and above all the CONSUMER of the projection in the same measurement -- t
 the k-sliced full-batch kernel (30.9 us back to back, but 31 MB of fp32 slabs to write and for the next norm to read)
 by 0.14 ms per step.  Which candidate the back-to-back search ranks first also varied from run to run.  So the finalists
 are re-ranked WHERE THEY RUN: for each projection of the largest graph batch in turn (biggest first) each candidate is
-made the plan, the graph is re-captured and a synthetic full batch replayed; the fastest stays.
+made the plan, the graph is re-captured and a synthetic full batch replayed (median of 20 individually timed replays).
+A challenger replaces the search's pick only if it is faster by `margin` (0.5 %) AND wins a confirmation round against a
+fresh measurement of the incumbent by the same margin (round 3 ranked on the mean of 6 replays with a 0.2 % threshold:
+inside run-to-run noise, plans flipped between runs).
 
 Used by this repository's engine (engine.Engine.refine_plans_in_graph) and, through `minisgl_plugin.install()`, by the
 reference's GraphRunner (P/engine/graph.py:105-150) -- the same function, handed the host's own Req / Batch types and
@@ -25,7 +28,7 @@ from . import ops
 def refine_plans_in_graph(*, bs: int, page_table: torch.Tensor, page_size: int, num_pages: int, row_len: int,
                           device: torch.device, Req: Any, Batch: Any, prepare_metadata: Callable[[Any], None],
                           capture: Callable[[], None], replay: Callable[[Any], Any], forward_ctx: Callable[[Any], Any],
-                          mean_context: int = 900, replays: int = 6) -> List[dict]:
+                          mean_context: int = 900, replays: int = 20, margin: float = 0.005) -> List[dict]:
     """Returns one dict per refined projection: step times (ms) per candidate, the one kept, whether it changed.
     Nothing happens (empty list) when no shape of batch `bs` has more than one candidate or the KV pool cannot hold the
     synthetic batch (bs requests of up to 2 * mean_context tokens in contiguous slots; K/V contents are left as they
@@ -49,17 +52,27 @@ def refine_plans_in_graph(*, bs: int, page_table: torch.Tensor, page_size: int, 
     prepare_metadata(batch)
 
     def measure() -> float:
+        """Re-capture with the plans in force, then the MEDIAN of `replays` individually timed replays (one event pair
+        each: a clock ramp or a stray host stall moves single samples, not the median)."""
         capture()
         with forward_ctx(batch):
             replay(batch)
             replay(batch)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(replays):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(replays + 1)]
+            evs[0].record()
+            for i in range(replays):
                 replay(batch)
-            e1.record()
-            e1.synchronize()
-        return e0.elapsed_time(e1) / replays
+                evs[i + 1].record()
+            evs[-1].synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+        return ts[len(ts) // 2]
+
+    def forget_pending() -> None:
+        # a candidate that failed mid-forward may have left a deferred reduce / all-reduce registered: the next capture
+        # must not trip over it
+        dev = device.index or 0
+        ops._PENDING_SLABS[dev] = None
+        ops._PENDING_ALLREDUCE[dev] = None
 
     report = []
     try:
@@ -67,23 +80,40 @@ def refine_plans_in_graph(*, bs: int, page_table: torch.Tensor, page_size: int, 
         for key in sorted(keys, key=lambda k: -k[2] * k[3]):  # biggest projection first
             info = ops._CANDIDATES[key]
             snap, start = ops.snapshot_plan(key), ops.current_candidate(key)
-            best_ms, best_spec, tried = base, None, {"(search's pick) " + start: round(base, 4)}
+            best_ms, best_spec, best_label, tried = base, None, None, {"(search's pick) " + start: round(base, 4)}
             for label, spec in info["cands"]:
                 try:
                     ops.apply_candidate(key, spec)
                     ms = measure()
                 except Exception as e:  # a candidate that cannot be captured is skipped, never fatal
-                    tried[label] = type(e).__name__
+                    forget_pending()
+                    tried[label] = f"{type(e).__name__}: {e}"[:160]
                     continue
                 tried[label] = round(ms, 4)
-                if ms < best_ms * 0.998:
-                    best_ms, best_spec = ms, spec
+                if ms < best_ms:
+                    best_ms, best_spec, best_label = ms, spec, label
             ops.restore_search_pick(key, snap)
-            if best_spec is not None:
-                ops.apply_candidate(key, best_spec)
-            base = best_ms
-            report.append(dict(name=info["name"], M=key[1], N=key[2], K=key[3], step_ms=tried,
-                               chosen=ops.current_candidate(key), changed=best_spec is not None))
+            accepted = False
+            if best_spec is not None and best_ms < base * (1.0 - margin):
+                # confirmation round, incumbent first: box clocks drift over the seconds a sweep takes, so the challenger
+                # must win again against a fresh measurement of the incumbent, by the same margin
+                try:
+                    base2 = measure()
+                    ops.apply_candidate(key, best_spec)
+                    ms2 = measure()
+                    tried["confirm: incumbent / " + best_label] = [round(base2, 4), round(ms2, 4)]
+                    accepted = ms2 < base2 * (1.0 - margin)
+                    if accepted:
+                        base = ms2
+                    else:
+                        ops.restore_search_pick(key, snap)
+                        base = base2
+                except Exception as e:
+                    forget_pending()
+                    ops.restore_search_pick(key, snap)
+                    tried["confirm"] = f"{type(e).__name__}: {e}"[:160]
+            report.append(dict(name=info["name"], M=key[1], N=key[2], K=key[3], step_ms=tried, replays=replays, margin=margin,
+                               chosen=ops.current_candidate(key), changed=accepted))
         capture()  # the graph that stays = the plans that stay
     finally:
         page_table[:bs, :L] = saved

@@ -49,3 +49,23 @@ def fmt(stats: Dict[str, float]) -> str:
     return (f"n={stats['n']} ref_std={stats['ref_std']:.3f} |err| max={stats['max_abs']:.2e} p99={stats['p99_abs']:.2e} "
             f"mean={stats['mean_abs']:.2e} frac>1e-3={stats['frac_gt_1e3']:.3f} | ulp(bf16 of ref) max="
             f"{stats['max_ulp']:.2f} p99={stats['p99_ulp']:.2f} mean={stats['mean_ulp']:.3f}")
+
+
+def floor_report(label: str, ours: Dict[str, float], floor: Dict[str, float], ours_agree: int, floor_agree: int, total: int) -> str:
+    return (f"[{label}] vs the fp32 oracle, same teacher-forced batches:\n"
+            f"    ours        {fmt(ours)}; argmax agreement {ours_agree}/{total}\n"
+            f"    torch-bf16  {fmt(floor)}; argmax agreement {floor_agree}/{total}\n"
+            f"    ratio ours / torch-bf16: max {ours['max_abs'] / max(floor['max_abs'], 1e-12):.2f}  p99 "
+            f"{ours['p99_abs'] / max(floor['p99_abs'], 1e-12):.2f}  mean {ours['mean_abs'] / max(floor['mean_abs'], 1e-12):.2f}")
+
+
+def assert_not_above_bf16_floor(label: str, ours: Dict[str, float], floor: Dict[str, float], ours_agree: int, floor_agree: int,
+                                total: int) -> None:
+    """|ours - oracle| must be statistically no larger than |independent torch-bf16 forward - oracle| (oracle/torch_bf16.py):
+    mean and p99 within 25 % of the floor's, the maximum (one sample of the tail) within 50 %, and the argmax of ours
+    agrees with the oracle's at least as often as the floor's does (minus 1 % of the rows for ties broken the other way)."""
+    print(floor_report(label, ours, floor, ours_agree, floor_agree, total))
+    assert ours["mean_abs"] <= 1.25 * floor["mean_abs"] + 1e-7, label
+    assert ours["p99_abs"] <= 1.25 * floor["p99_abs"] + 1e-7, label
+    assert ours["max_abs"] <= 1.5 * floor["max_abs"] + 1e-7, label
+    assert ours_agree >= floor_agree - max(2, total // 100), label

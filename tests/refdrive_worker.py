@@ -91,6 +91,47 @@ def replay_through_repo_engine(spec, forwards, ref_engine, tp_rank, tp_size, rec
     return out
 
 
+def gated_mlp_checks(plugin, engine, model_dir):
+    """a GatedMLP whose gate_up rows the plugin interleaved must never take the reference forward on
+    them.  Inputs the fused path used to hand to the reference forward (3-D, non-contiguous), the un-permute helpers, and
+    a weight REPLACED by load_state_dict-style setattr (P/layers/base.py:31-49)."""
+    import torch
+    from safetensors.torch import load_file
+
+    layers = engine.model.model.layers.op_list
+    m0, m1 = layers[0].mlp, layers[1].mlp
+    out = dict(interleaved=bool(getattr(m0, "_msgl_gate_up_ilv", False) and getattr(m1, "_msgl_gate_up_ilv", False)))
+    if not out["interleaved"]:
+        return out
+    state = load_file(str(Path(model_dir) / "model.safetensors"))
+    hf = [torch.cat([state[f"model.layers.{i}.mlp.gate_proj.weight"], state[f"model.layers.{i}.mlp.up_proj.weight"]], 0).to(engine.device)
+          for i in (0, 1)]
+    H = hf[0].shape[1]
+    g = torch.Generator(device=engine.device).manual_seed(5)
+    x = torch.randn((5, H), generator=g, device=engine.device).to(torch.bfloat16)
+    wide = torch.randn((5, 2 * H), generator=g, device=engine.device).to(torch.bfloat16)
+    y0 = m0.forward(x)
+    out["three_d_equal"] = bool(torch.equal(m0.forward(x.view(1, 5, H)), y0.view(1, 5, -1)))
+    xs = wide[:, ::2]  # stride(1) == 2
+    out["strided_equal"] = bool(torch.equal(m0.forward(xs), m0.forward(xs.contiguous())))
+    out["reference_layout_equal"] = bool(torch.equal(plugin.gate_up_reference(m0), hf[0]))
+    y1 = m1.forward(x)
+    # a reload replaces the tensor object (reference layout): the layer must turn back into a plain reference layer
+    m1.gate_up_proj.weight = hf[1].clone()
+    y1b = m1.forward(x)
+    out["replaced_flag_cleared"] = not getattr(m1, "_msgl_gate_up_ilv", True)
+    out["replaced_max_abs"] = float((y1b.float() - y1.float()).abs().max())
+    out["out_absmax"] = float(y1.float().abs().max())
+    # restore everything in place: rows back to [gate; up], flags cleared, outputs unchanged
+    out["restored_layers"] = plugin.restore_gate_up_layout(engine.model)
+    out["restored_equal_hf"] = bool(torch.equal(m0.gate_up_proj.weight, hf[0]))
+    out["restored_max_abs"] = float((m0.forward(x).float() - y0.float()).abs().max())
+    out["reinterleaved"] = plugin._interleave_gated_mlps(engine.model)
+    out["reinterleaved_equal"] = bool(torch.equal(m0.forward(x), y0))
+    torch.cuda.synchronize()
+    return out
+
+
 def main() -> None:
     spec_path, out_path, ref_root = sys.argv[1:4]
     spec = json.loads(Path(spec_path).read_text())
@@ -282,6 +323,8 @@ def main() -> None:
         rec["comm_has_side"] = getattr(comm, "side", None) is not None
     if spec.get("replay_repo_engine"):
         rec["repo_replay"] = replay_through_repo_engine(spec, forwards, engine, tp_rank, tp_size, rec)
+    if spec.get("mlp_checks"):
+        rec["mlp_checks"] = gated_mlp_checks(plugin, engine, model_dir)
     try:
         cm.check_integrity()
         rec["integrity"] = "ok"

@@ -258,9 +258,10 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert L.msgl_attn_decode_workspace_bytes(64, 40, 128) == 64 * 40 * 130 * 4
     assert L.msgl_fast_compare_key(None, 3, None, 3, 4) == -1
     # round-3 entry points: tile rows per prefill kernel, fused gate_up + SiLU.mul, slab-only weight-streaming GEMM
-    assert L.msgl_attn_prefill_q_tile(0) == 128 and L.msgl_attn_prefill_q_tile(4) == 128 and L.msgl_attn_prefill_q_tile(5) == 256
-    assert L.msgl_attn_prefill(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 1, 1, 8, 2, 128, 1024, 256, 128, 1024, 0.1,
-                               0, None, 7, None) == -1  # unknown kernel code
+    assert L.msgl_attn_prefill_q_tile(0) == 128 and L.msgl_attn_prefill_q_tile(4) == 128 and L.msgl_attn_prefill_q_tile(2) == 128
+    for code in (7, 1, 3, 5, 16, 17, 64, 65, 128, -1):  # unknown / removed generations / ablation codes of a diagnostic build
+        assert L.msgl_attn_prefill(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 1, 1, 8, 2, 128, 1024, 256, 128, 1024, 0.1,
+                                   0, None, code, None) == -1, code
     assert L.msgl_attn_prefill(p16, p16, p16, p16, p16, 32, None, p16, p16, p16, 1, 1, 8, 2, 128, 1024, 1 << 33, 128, 1024,
                                0.1, 0, None, 0, None) == -1  # token stride beyond the 32-bit slot-offset multiply
     assert L.msgl_skinny_gemm_silu_nt(p16, p16, p16, 4, 256, 128, 128, 128, 128, 0, 2, 3, None) == -1  # row tiles 1, 2, 4

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import parity_stats
-from oracle import ref_model, ref_ops
+from oracle import ref_model, ref_ops, torch_bf16
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def make_engine(dev, name="tiny", fused=True, graphs=True, page_size=4, seed=42)
                        cuda_graph_bs=[1, 2, 4, 8] if graphs else [], max_seq_len_override=512,
                        num_page_override=4096 // page_size, fused_qkv_path=fused, seed=seed)
     eng = Engine(cfg, dev)
-    eng.kv_cache._kv_buffer.zero_()  # torch.empty pool: make untouched slots comparable across engines
+    eng.kv_cache.pool.zero_()  # torch.empty pool: make untouched slots comparable across engines
     return eng
 
 
@@ -75,12 +75,12 @@ def test_fused_path_is_bit_identical_to_reference_op_order(dev, name):
     ps = prompts(6)
     e1 = make_engine(dev, name, fused=True, graphs=False)
     ids1, _, _ = run(e1, ps, 6)
-    kv1 = e1.kv_cache._kv_buffer.clone()
+    kv1 = e1.kv_cache.pool.clone()
     e1.shutdown()
     e2 = make_engine(dev, name, fused=False, graphs=False)
     ids2, _, _ = run(e2, ps, 6)
     assert ids1 == ids2
-    assert torch.equal(kv1[:, :, :-1].cpu(), e2.kv_cache._kv_buffer[:, :, :-1].cpu())  # all but the dummy page
+    assert torch.equal(kv1[:, :, :-1].cpu(), e2.kv_cache.pool[:, :, :-1].cpu())  # all but the dummy page
     e2.shutdown()
 
 
@@ -133,14 +133,22 @@ def test_teacher_forced_parity_vs_cpu_oracle(dev, name, page_size):
     cfg = eng.cfg.model
     w = ref_model.weights_from_device_model(eng.model)
     table = eng.page_table.cpu()
-    slots = eng.kv_cache._kv_buffer.shape[2] * eng.kv_cache._kv_buffer.shape[3]
+    slots = eng.kv_cache.pool.shape[2] * eng.kv_cache.pool.shape[3]
     kp = [torch.zeros((slots, cfg.num_kv_heads, cfg.head_dim), dtype=torch.bfloat16) for _ in range(cfg.num_layers)]
     vp = [torch.zeros_like(k) for k in kp]
-    agree = total = 0
-    stats = {}
+    agree = total = floor_agree = 0
+    stats, floor = {}, {}
+    # the independent bf16 forward (plain torch ops on the GPU, oracle/torch_bf16.py): where a bf16 pipeline sits
+    wd, table_d = torch_bf16.weights_to(w, dev), table.to(dev)
+    kpd = [torch.zeros_like(k, device=dev) for k in kp]
+    vpd = [torch.zeros_like(k) for k in kpd]
     for r in rec:
         logits = ref_model.forward(cfg, w, r["input_ids"], r["positions"], r["out_loc"], kp, vp, table, r["rows"],
                                    r["k_lens"], r["q_lens"], r["phase"] == "prefill").float()[: r["size"]]
+        tb = torch_bf16.forward(cfg, wd, r["input_ids"].to(dev), r["positions"].to(dev), r["out_loc"].to(dev), kpd, vpd, table_d,
+                                r["rows"], r["k_lens"], r["q_lens"], r["phase"] == "prefill").float().cpu()[: r["size"]]
+        floor = parity_stats.merge_stats(floor, parity_stats.logit_error_stats(tb, logits))
+        floor_agree += int((tb.argmax(-1) == logits.argmax(-1)).sum())
         st = parity_stats.logit_error_stats(r["logits"], logits)
         stats = parity_stats.merge_stats(stats, st)
         assert st["max_abs"] <= LOGIT_TOL, parity_stats.fmt(st)
@@ -152,8 +160,9 @@ def test_teacher_forced_parity_vs_cpu_oracle(dev, name, page_size):
         total += same.numel()
     print(f"\n[teacher-forced {name} page {page_size}] {parity_stats.fmt(stats)}; argmax agreement {agree}/{total}")
     assert agree >= 0.9 * total and stats["p99_abs"] <= LOGIT_TOL / 2
+    parity_stats.assert_not_above_bf16_floor(f"{name}, {cfg.num_layers} layers", stats, floor, agree, floor_agree, total)
     # KV pool contents: every slot the run wrote agrees with the oracle's pool
-    dev_k = eng.kv_cache._kv_buffer[0].cpu().view(cfg.num_layers, slots, cfg.num_kv_heads, cfg.head_dim)
+    dev_k = eng.kv_cache.pool[0].cpu().view(cfg.num_layers, slots, cfg.num_kv_heads, cfg.head_dim)
     for li in range(cfg.num_layers):
         torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=3e-2, rtol=3e-2)
     eng.shutdown()
@@ -199,7 +208,7 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
     cfg = EngineConfig(model=PRESETS["qwen3-0.6b"], dtype=torch.bfloat16, max_running_req=4, page_size=page_size,
                        cuda_graph_bs=[1], max_seq_len_override=256, num_page_override=1024 // page_size, seed=42)
     eng = Engine(cfg, dev)
-    eng.kv_cache._kv_buffer.zero_()
+    eng.kv_cache.pool.zero_()
     rnd = random.Random(0)
     prompt = [rnd.randint(0, 10000) for _ in range(32)]
     rec = []
@@ -210,16 +219,24 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
     m = eng.cfg.model
     w = ref_model.weights_from_device_model(eng.model)
     table = eng.page_table.cpu()
-    slots = eng.kv_cache._kv_buffer.shape[2] * eng.kv_cache._kv_buffer.shape[3]
+    slots = eng.kv_cache.pool.shape[2] * eng.kv_cache.pool.shape[3]
     kp = [torch.zeros((slots, m.num_kv_heads, m.head_dim), dtype=torch.bfloat16) for _ in range(m.num_layers)]
     vp = [torch.zeros_like(k) for k in kp]
     row = rec[0]["rows"][0]
-    sure_n = same_n = 0
+    sure_n = same_n = floor_same = 0
+    floor = {}
+    wd, table_d = torch_bf16.weights_to(w, dev), table.to(dev)
+    kpd = [torch.zeros_like(k, device=dev) for k in kp]
+    vpd = [torch.zeros_like(k) for k in kpd]
     for step, r in enumerate(rec):
         # KV block indices: the slots this forward writes are the table's entries for its positions
         assert torch.equal(r["out_loc"].long(), table[row, r["positions"].long()].long())
         logits = ref_model.forward(m, w, r["input_ids"], r["positions"], r["out_loc"], kp, vp, table, r["rows"],
                                    r["k_lens"], r["q_lens"], r["phase"] == "prefill").float()[: r["size"]]
+        tb = torch_bf16.forward(m, wd, r["input_ids"].to(dev), r["positions"].to(dev), r["out_loc"].to(dev), kpd, vpd, table_d,
+                                r["rows"], r["k_lens"], r["q_lens"], r["phase"] == "prefill").float().cpu()[: r["size"]]
+        floor = parity_stats.merge_stats(floor, parity_stats.logit_error_stats(tb, logits))
+        floor_same += int(tb.argmax(-1)[0]) == int(logits.argmax(-1)[0])
         st = parity_stats.logit_error_stats(r["logits"], logits)
         dist = parity_stats.merge_stats(dist, st)
         assert st["max_abs"] <= tol, (step, parity_stats.fmt(st))
@@ -234,7 +251,8 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
     print(f"\n[config 0, Qwen3-0.6B dims, page {page_size}] {parity_stats.fmt(dist)}; greedy ids equal at {same_n}/{len(rec)} "
           f"steps ({sure_n} with a sure oracle margin)")
     assert dist["p99_abs"] <= tol / 2 and dist["mean_ulp"] <= 8.0
-    dev_k = eng.kv_cache._kv_buffer[0].cpu().view(m.num_layers, slots, m.num_kv_heads, m.head_dim)
+    parity_stats.assert_not_above_bf16_floor(f"Qwen3-0.6B dims, 28 layers, page {page_size}", dist, floor, same_n, floor_same, len(rec))
+    dev_k = eng.kv_cache.pool[0].cpu().view(m.num_layers, slots, m.num_kv_heads, m.head_dim)
     for li in (0, m.num_layers // 2, m.num_layers - 1):  # one bf16 ulp of a K element of magnitude 4 is 3e-2
         torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=tol, rtol=tol)
     eng.shutdown()

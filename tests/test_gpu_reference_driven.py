@@ -191,10 +191,17 @@ def test_reference_driven_radix_chunked_prefill_and_repeats_tiny(dev, model_dirs
               num_page_override=4096 // page_size, max_extend_tokens=64, cache_type="radix")
     rounds = [dict(prompts=ps, sampling=[greedy(6)] * len(ps)) for ps in tiny_rounds()]
     rec = refdrive.run_worker(dict(model="tiny", model_dir=mdir, llm_kwargs=kw, rounds=rounds,
-                                   full_logits_forwards=10 ** 9, max_position=4096))
+                                   full_logits_forwards=10 ** 9, max_position=4096, mlp_checks=page_size == 16))
     assert rec["backend"] == "HipAttnBackend" and rec["integrity"] == "ok"
     fw = rec["forwards"]
     assert all(len(o) == 6 for r in rec["outputs"] for o in r)
+    if page_size == 16:  # the plugin's interleaved GatedMLP never takes the reference forward on permuted rows
+        mc = rec["mlp_checks"]
+        print(f"\n[refdrive tiny] interleaved GatedMLP checks: {mc}")
+        assert mc["interleaved"] and mc["three_d_equal"] and mc["strided_equal"] and mc["reference_layout_equal"]
+        assert mc["replaced_flag_cleared"] and mc["replaced_max_abs"] <= 2.0 ** -7 * mc["out_absmax"]
+        assert mc["restored_layers"] >= 1 and mc["restored_equal_hf"] and mc["restored_max_abs"] <= 2.0 ** -7 * mc["out_absmax"]
+        assert mc["reinterleaved"] >= 2 and mc["reinterleaved_equal"]
     # the scheduler really did what the scenario is about
     assert any(any(f["chunked"]) for f in fw), "no chunked prefill happened"
     hits = [f for f in fw if f["phase"] == "prefill" and any(c > 0 and not ch for c, ch in zip(f["cached_lens"], f["chunked"]))]

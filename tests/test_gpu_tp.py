@@ -70,10 +70,13 @@ def test_p2p_collectives_known_answers(dev, world):
 def test_p2p_barrier_timeout_poisons_and_raises(dev):
     """comm_p2p.hip: a barrier whose peer never arrives gives up after the spin limit; the collective's output is
     NaN-poisoned instead of a partial sum, the error word is sticky (later collectives fail fast), and every host poll
-    (sync, async, destroy) raises MsglError.  The rank that stayed away is untouched."""
+    (sync, async, destroy) raises MsglError.  The rank that gave up also writes its verdict into the PEERS' headers
+    (ADVICE r3): a live but lagging peer must not pass its barriers later and sum staging areas the failed rank has
+    meanwhile rewritten -- it poisons from its next barrier on and its host raises at its next poll."""
     r0, r1 = launch("absent_rank", 2, timeout=180.0)
     assert r0["two_shot_all_nan"] and r0["one_shot_all_nan"] and r0["gather_all_nan"], r0
-    assert r0["error_word"] != 0 and r1["error_word"] == 0
+    assert r0["error_word"] != 0 and r1["error_word"] == r0["error_word"], (r0["error_word"], r1["error_word"])
+    assert r1["late_all_nan"] and r1["late_raised"] and "gave up waiting" in r1["late_raised"]
     assert r0["raised"]["sync"] and "gave up waiting" in r0["raised"]["sync"]
     assert r0["raised"]["async"] and "gave up waiting" in r0["raised"]["async"]
     assert r0["destroy_raised"]

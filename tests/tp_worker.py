@@ -181,7 +181,20 @@ def absent_rank(rank: int, world: int, dev: torch.device) -> dict:
             res["destroy_raised"] = True
     dist.barrier()
     if rank != 0:
+        # the rank that stayed away: rank 0's verdict arrived in its header, so a collective it enters NOW (alone: rank 0 is
+        # done) poisons at once instead of spinning, and its host's poll raises
         res["error_word"] = comm.error()
+        x = torch.full((256 * 1024,), 1.0, dtype=torch.bfloat16, device=dev)
+        t0 = time.perf_counter()
+        comm.all_reduce(x)
+        torch.cuda.synchronize()
+        res["late_seconds"] = time.perf_counter() - t0
+        res["late_all_nan"] = bool(x.isnan().all())
+        try:
+            comm.poll_error(sync=True)
+            res["late_raised"] = None
+        except MsglError as e:
+            res["late_raised"] = str(e)
         comm.destroy()
     return res
 
@@ -207,7 +220,7 @@ def tp_model(rank: int, world: int, dev: torch.device) -> dict:
                            tp_cpu_group=dist.group.WORLD if tp_size > 1 else None, gemm_tune="off")
         eng = Engine(cfg, dev)
         eng.model.load_hf_state(state)
-        eng.kv_cache._kv_buffer.zero_()
+        eng.kv_cache.pool.zero_()
         return eng
 
     def run(tp_size, tp_rank, comm, comm_side, split, overlap):
@@ -219,7 +232,7 @@ def tp_model(rank: int, world: int, dev: torch.device) -> dict:
         record_offline_runner(runner, eng, forwards)
         runner.generate(prompts, sp)
         ids = [runner.output_ids(s) for s in runner.last_states]
-        kv = eng.kv_cache._kv_buffer.cpu()
+        kv = eng.kv_cache.pool.cpu()
         eng.shutdown()
         return dict(ids=ids, forwards=forwards, logits=[f["logits"] for f in forwards], kv=kv)
 
@@ -229,7 +242,7 @@ def tp_model(rank: int, world: int, dev: torch.device) -> dict:
 
         eng = engine(1, 0, None, None, 0, True)
         logits = [replay_forward(eng, f).float().cpu() for f in forwards]
-        kv = eng.kv_cache._kv_buffer.cpu()
+        kv = eng.kv_cache.pool.cpu()
         eng.shutdown()
         return dict(logits=logits, kv=kv)
 

@@ -133,7 +133,7 @@ def run_prefill(res, dev):
     for name, ql, kl, hq, hkv, page in cases:
         c = prefill_case(ql, kl, hq, hkv, page, dev)
         r = dict(flops=c["flops"], tokens=c["T"], requests=c["B"], q_tiles=c["total_tiles"])
-        for label, impl, order in (("dma_heavy", 4, c["order"]), ("dma_natural", 4, None), ("tr_heavy", 2, c["order"]), ("gen1", 1, None)):
+        for label, impl, order in (("dma_heavy", 4, c["order"]), ("dma_natural", 4, None), ("tr_heavy", 2, c["order"])):
             f = lambda: ops.attn_prefill(c["out"], c["q"], c["k"], c["v"], c["table"], None, c["seq"], c["cu_q"],  # noqa: E731
                                          c["tile_cu"], c["B"], c["total_tiles"], 128 ** -0.5, tile_order=order,
                                          impl=impl)

@@ -1,7 +1,9 @@
-"""Where the prefill attention kernel's time goes: the tr-read kernel (csrc/attn_prefill.hip, impl 2) with parts of its
-loop removed (impl 16 + bits; results are wrong by construction, timing only).
+"""Where the prefill attention kernels' time goes: the register-staged kernel (csrc/attn_prefill.hip, impl 2) and the
+DMA-staged default (impl 4) with parts of their loops removed (impl 16 + bits / 64 + bits; results are wrong by
+construction, timing only).  The ablation variants exist only in a diagnostic build of the library:
 
-    python tools/prefill_ablate.py [--out gpurun_out/prefill_ablate.json]
+    MSGL_PREFILL_DIAG=1 python mini-sglang_amd/build.py --force && python tools/prefill_ablate.py [--out gpurun_out/prefill_ablate.json]
+    python tools/prefill_ablate.py --only "tr: full" "dma: full"          (production build: the two kernels, no ablations)
 
 bits: 1 = K/V tile loaded once (no global loads / LDS writes in the loop), 2 = no QK^T MFMAs (and no K fragment reads),
 4 = no softmax arithmetic, 8 = no PV MFMAs (and no V^T fragment reads), 16 = no barrier in the loop.
@@ -32,11 +34,6 @@ DMA_VARIANTS = {0: "full", 16: "full, s_setprio 1 on the MFMA blocks", 32: "full
                 10: "softmax + stream", 14: "stream + barrier only", 15: "loop skeleton"}
 
 
-PP_VARIANTS = {11: "softmax only (no MFMA, no LDS reads, no stream)", 5: "MFMA + LDS reads only (no softmax, no stream)", 0: "full", 16: "full, softmax segment at priority 1", 32: "full, matrix segment at priority 1",
-               64: "full, group B at priority 1", 1: "no K/V stream", 4: "no softmax", 2: "no QK^T", 8: "no PV", 10: "softmax + stream",
-               14: "stream + barriers only", 15: "loop skeleton"}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/prefill_ablate.json")
@@ -52,24 +49,19 @@ def main():
     res = {}
     for name, ql, kl, hq, hkv in cases:
         c = prefill_case(ql, kl, hq, hkv, 256, dev)
-        c2 = prefill_case(ql, kl, hq, hkv, 256, dev, q_tile=256)
-        for k_ in ("q", "k", "v", "table"):
-            c2[k_] = c[k_]
 
         def launch(cc, impl):
             ops.attn_prefill(cc["out"], cc["q"], cc["k"], cc["v"], cc["table"], None, cc["seq"], cc["cu_q"], cc["tile_cu"],
                              cc["B"], cc["total_tiles"], 128 ** -0.5, tile_order=cc["order"], impl=impl)
 
         row, outs = {}, {}
-        for impl, cc in ((2, c), (4, c), (5, c2)):
+        for impl, cc in ((2, c), (4, c)):
             cc["out"].zero_()
             launch(cc, impl)
             outs[impl] = cc["out"].clone()
         row["dma == tr (bitwise)"] = bool(torch.equal(outs[2], outs[4]))
-        row["pp == tr (bitwise)"] = bool(torch.equal(outs[2], outs[5]))
         runs = [("tr: " + label, c, (16 + bits) if bits else 2) for bits, label in VARIANTS.items()]
         runs += [("dma: " + label, c, (64 + bits) if bits else 4) for bits, label in DMA_VARIANTS.items()]
-        runs += [("pp: " + label, c2, (128 + bits) if bits else 5) for bits, label in PP_VARIANTS.items()]
         if args.only:
             runs = [r for r in runs if any(r[0].startswith(o) for o in args.only)]
         best = {}
@@ -81,7 +73,7 @@ def main():
             row[label] = dict(us=round(us, 1), frac_if_full=round(c["flops"] / us / 1e6 / MFMA_PEAK_TFLOPS, 3))
         res[name] = dict(flops=c["flops"], q_tiles=c["total_tiles"], variants=row)
         print(name, json.dumps(row), flush=True)
-        del c, c2
+        del c
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(res, indent=1))
 

@@ -94,7 +94,7 @@ def run(model: str, tp: int, batch: int, steps: int, warmup: int, page_size: int
     sp = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=steps + warmup + 8) for _ in range(B)]
     states = [runner.add_request(p, s) for p, s in zip(prompts, sp)]
     # contexts are filled with random K/V (no prefill: the shard's prefill is not what this bounds)
-    engine.kv_cache._kv_buffer.normal_(0.0, 1.0)
+    engine.kv_cache.pool.normal_(0.0, 1.0)
     for st in states:
         st.req.cached_len, st.req.device_len = st.prompt_len - 1, st.prompt_len
     runner._allocate_paged([type("R", (), dict(table_idx=s.req.table_idx, cached_len=0, device_len=s.prompt_len))()

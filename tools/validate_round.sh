@@ -69,16 +69,15 @@ find $R/gpurun_out/${TAG}_pmc_mfma -name "*.db" -delete
 # prefill attention: kernel generations timed interleaved + the default kernel's ablations, wave-level counters, segment stamps of
 # the counter-phase kernel; fused gate_up + SiLU.mul of the weight-streaming kernel against projection + activation
 cd $R
-timeout 200 python tools/prefill_ablate.py --rounds 3 --only "tr: full" "dma: " "pp: full" --out gpurun_out/${TAG}_prefill_variants.json > gpurun_out/${TAG}_prefill_variants.log 2>&1
+timeout 200 python tools/prefill_ablate.py --rounds 3 --only "tr: full" "dma: full" --out gpurun_out/${TAG}_prefill_variants.json > gpurun_out/${TAG}_prefill_variants.log 2>&1
 python - <<PY
 import json
 try:
     r = json.load(open("gpurun_out/${TAG}_prefill_variants.json"))
     for n, c in r.items():
-        print(n, {k: v["frac_if_full"] for k, v in c["variants"].items() if isinstance(v, dict) and k in ("tr: full", "dma: full", "pp: full")})
+        print(n, {k: v["frac_if_full"] for k, v in c["variants"].items() if isinstance(v, dict) and k in ("tr: full", "dma: full")})
 except Exception as e:
     print("prefill variants unreadable:", e)
 PY
-timeout 300 bash tools/pmc_prefill.sh ${TAG} 2 4 5 > gpurun_out/${TAG}_pmc_prefill.log 2>&1; grep -c "SQ_" gpurun_out/${TAG}_pmc_prefill.txt
-timeout 100 python tools/prefill_trace.py --out gpurun_out/${TAG}_prefill_trace_pp.json 2>&1 | grep group | cut -c1-300
+timeout 300 bash tools/pmc_prefill.sh ${TAG} 2 4 > gpurun_out/${TAG}_pmc_prefill.log 2>&1; grep -c "SQ_" gpurun_out/${TAG}_pmc_prefill.txt
 timeout 100 python tools/skinny_silu_bench.py --out gpurun_out/${TAG}_skinny_silu_bench.json 2>&1 | tail -3 | cut -c1-200
