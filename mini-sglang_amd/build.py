@@ -97,7 +97,8 @@ def build_all(force: bool = False, verbose: bool = True) -> dict[str, Path]:
     out = {}
     lib_hip = LIB / "libmsgl_hip.so"
     if force or _stale(lib_hip, hip_objs):
-        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, hip_objs), "-o", str(lib_hip)])
+        # --no-undefined: a kernel whose host-side launch stub went missing must fail HERE, not at dlopen on the GPU box
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,--no-undefined", *map(str, hip_objs), "-o", str(lib_hip)])
     out["hip"] = lib_hip
     if comm_objs:
         lib_comm = LIB / "libmsgl_comm.so"

@@ -59,6 +59,12 @@ constexpr int kG3LdsBytes = kG3Stages * kG3Stage;  // 144 KB
 
 enum { G3_EPI_OUT = 0, G3_EPI_SILU = 1 };
 
+// DMA pieces per step of one loader wave: x pieces, w pieces, loader waves per role
+template <bool SPLIT>
+struct G3Loaders {
+  static constexpr int kNX = SPLIT ? 16 : 8, kNW = SPLIT ? 8 : 4, kNL = SPLIT ? 2 : 4;
+};
+
 // ABL (diagnosis): 1 = no x loads, 2 = no compute, 4 = no w loads, 8 = no epilogue stores.  WPOL = cache policy bits of the weight DMA
 // (0 default, 2 = nt).  SPOL = cache policy bits of the k-slice slab stores (0 plain, 16 = sc1 write-through, 2 = nt).
 // SPLITLD: loader waves 4-5 issue only the x pieces, waves 6-7 only the w pieces (the L2-hit stream and the HBM stream in
@@ -81,10 +87,12 @@ __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
     // piece p of the x tile = rows [8 p, 8 p + 8) (32 pieces), of the w tile likewise (16 pieces).  Default: loader L takes
     // x pieces 4 i + L (i < 8) and w pieces 4 i + L (i < 4).  SPLITLD: loaders 0, 1 take x pieces 2 i + L (i < 16), loaders
     // 2, 3 take w pieces 2 i + (L - 2) (i < 8).
-    constexpr int kNX = SPLITLD ? 16 : 8, kNW = SPLITLD ? 8 : 4, kNL = SPLITLD ? 2 : 4;
+    // (hipcc / ROCm 7.2: a local array whose BOUND depends on a template parameter makes the host pass silently drop the
+    // kernel's launch stub -- the library then fails to load with an undefined __device_stub__ symbol.  Fixed bounds below.)
+    constexpr int kNX = G3Loaders<SPLITLD>::kNX, kNW = G3Loaders<SPLITLD>::kNW, kNL = G3Loaders<SPLITLD>::kNL;
     const bool xrole = !SPLITLD || L < 2, wrole = !SPLITLD || L >= 2;
     const int LL = SPLITLD ? (L & 1) : L;
-    int xvo[kNX], wvo[kNW];
+    int xvo[16], wvo[8];  // (fixed bounds; only the first kNX / kNW entries exist after unrolling)
 #pragma unroll
     for (int i = 0; i < kNX; ++i) {
       const int row = (kNL * i + LL) * 8 + drow;
