@@ -245,7 +245,7 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
                         max_seq_len_override=max_seq, comm=comm, comm_side=comm_side, memory_ratio=0.9,
                         # ranks sharing one GPU cannot each take 90 % of its memory: a fixed pool that holds the batch
                         num_page_override=(B * (max_seq // 2) // args.page_size) if share_gpu else None,
-                        comm_split_tokens=2048 if world > 1 else 0, tp_cpu_group=dist.group.WORLD if world > 1 else None,
+                        comm_split_tokens=int(os.environ.get("MSGL_BENCH_COMM_SPLIT", "2048")) if world > 1 else 0, tp_cpu_group=dist.group.WORLD if world > 1 else None,
                         gemm_tune=os.environ.get("MSGL_GEMM_TUNE", "full"))
     engine, err = None, None
     try:

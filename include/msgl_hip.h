@@ -401,9 +401,12 @@ int msgl_p2p_all_gather(msgl_p2p_t comm, void* dst, const void* src, size_t coun
 int msgl_p2p_all_reduce_add_rmsnorm(msgl_p2p_t comm, void* x, void* residual, const void* weight, float eps,
                                     int64_t rows, int64_t dim, int64_t x_stride, int64_t res_stride, int dtype,
                                     void* stream);
-/* A barrier that gives up (a peer did not arrive within the spin limit) sets a sticky error word (1 + phase) and the
- * kernel POISONS its output with NaN bit patterns instead of returning a partial sum; once the word is set every later
- * collective of the communicator poisons at once (no further spinning).  msgl_p2p_error reads the word (synchronises
+/* A barrier that gives up (a peer did not arrive within the spin limit) sets a sticky error word (bits 0-3: 1 + phase,
+ * 4-7: collective kind 1 one-shot / 2 two-shot / 3 fused norm / 4 all-gather, 8-15: block, 16-19: the peer waited for)
+ * in its own header AND in every peer's (there with bit 20 set and bits 16-19 = the rank that gave up), and the kernel
+ * POISONS its output with NaN bit patterns instead of returning a partial sum; once the word is set every later
+ * collective of the communicator -- on the failing rank and, from their next barrier on, on its peers -- poisons at once
+ * (no further spinning).  msgl_p2p_error reads the word (synchronises
  * the device); msgl_p2p_error_async enqueues a 4-byte copy of it into pinned host memory on `stream` for hosts that
  * poll every few steps (kernel.P2PCommunicator.poll_error raises).  msgl_p2p_set_spin_limit: polls per barrier before
  * giving up (default 40 M ~ tens of seconds). */

@@ -55,8 +55,12 @@ struct P2PPeers {
 // whose barrier gave up must never hand back a plausible partial sum (a lagging or dead peer would otherwise turn
 // into silently diverging replicas).  Once the error word is set no later barrier spins: every following collective
 // poisons at once and the host raises at its next poll (kernel.P2PCommunicator.poll_error).
+// Error word (sticky, 0 = healthy): bits 0-3 = 1 + barrier phase, 4-7 = collective kind (kP2PKind*), 8-15 = block index,
+// 16-19 = the peer whose flag never came, bit 20 = set on the copies a failing rank writes into its PEERS' headers.
+enum { kP2PKindOneShot = 1, kP2PKindTwoShot = 2, kP2PKindFusedNorm = 3, kP2PKindGather = 4 };
+
 __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int world, int phase, bool release,
-                                            uint32_t spin_limit, bool bad) {
+                                            uint32_t spin_limit, bool bad, int kind) {
   __shared__ int s_bad;
   P2PHeader* self = reinterpret_cast<P2PHeader*>(peers.base[rank]);
   const int b = blockIdx.x;
@@ -82,7 +86,9 @@ __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int
         break;
       }
       if (spins > spin_limit) {
-        __hip_atomic_store(&self->error, 1u + (uint32_t)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&self->error,
+                           (1u + (uint32_t)phase) | ((uint32_t)kind << 4) | (((uint32_t)b & 255u) << 8) | (threadIdx.x << 16),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         s_bad = 1;
         break;
       }
@@ -94,7 +100,9 @@ __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int
     // first block of this rank to see the failure: tell every peer (sticky there as here; their kernels poison from
     // their next barrier / next launch on, and their hosts raise at the next poll)
     P2PHeader* peer = reinterpret_cast<P2PHeader*>(peers.base[threadIdx.x]);
-    __hip_atomic_store(&peer->error, 1u + (uint32_t)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&peer->error,
+                       (1u + (uint32_t)phase) | ((uint32_t)kind << 4) | (((uint32_t)b & 255u) << 8) | ((uint32_t)rank << 16) | (1u << 20),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0) self->seq[b][phase] = seq;
   return out;
@@ -138,13 +146,13 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
     int64_t lo, hi;
     block_slice(packs, lo, hi);
     for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) mine[i] = data[i];
-    bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
+    bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad, TWO_SHOT ? kP2PKindTwoShot : kP2PKindOneShot);
     for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) {
       float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int r = 0; r < world; ++r) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes)[i]);
       data[i] = bad ? p2p_poison() : pack8f<T>(a);
     }
-    bad = p2p_barrier(peers, rank, world, 1, false, spin_limit, bad);  // nobody refills its copy while a peer still reads it
+    bad = p2p_barrier(peers, rank, world, 1, false, spin_limit, bad, TWO_SHOT ? kP2PKindTwoShot : kP2PKindOneShot);  // nobody refills its copy while a peer still reads it
     if (bad)
       for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) data[i] = p2p_poison();
   } else {
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
       block_slice(cn, lo, hi);
       for (int64_t i = c0 + lo + threadIdx.x; i < c0 + hi; i += kP2PThreads) mine[i] = data[i];
     }
-    bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
+    bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad, TWO_SHOT ? kP2PKindTwoShot : kP2PKindOneShot);
     // reduce-scatter: my chunk, summed in rank order, into my result area
     const int64_t m0 = min((int64_t)rank * chunk, packs), mn = min(chunk, packs - m0);
     int64_t lo, hi;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
       for (int r = 0; r < world; ++r) acc8<T>(a, reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes)[i]);
       res[i] = pack8f<T>(a);
     }
-    bad = p2p_barrier(peers, rank, world, 1, true, spin_limit, bad);
+    bad = p2p_barrier(peers, rank, world, 1, true, spin_limit, bad, TWO_SHOT ? kP2PKindTwoShot : kP2PKindOneShot);
     // all-gather of the reduced chunks from their owners
     for (int c = 0; c < world; ++c) {
       const int64_t c0 = min((int64_t)c * chunk, packs), cn = min(chunk, packs - c0);
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_reduce_kernel(P2PPeers pe
       const U4* src = reinterpret_cast<const U4*>(peers.base[c] + kP2PHeaderBytes) + area_packs;
       for (int64_t i = c0 + l2 + threadIdx.x; i < c0 + h2; i += kP2PThreads) data[i] = bad ? p2p_poison() : src[i];
     }
-    bad = p2p_barrier(peers, rank, world, 2, false, spin_limit, bad);
+    bad = p2p_barrier(peers, rank, world, 2, false, spin_limit, bad, TWO_SHOT ? kP2PKindTwoShot : kP2PKindOneShot);
     if (bad)
       for (int c = 0; c < world; ++c) {
         const int64_t c0 = min((int64_t)c * chunk, packs), cn = min(chunk, packs - c0);
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(1024) void p2p_all_reduce_add_rmsnorm_kernel(P2PPee
   // 1. copy my partial rows in (x may be row-strided; the staging image is dense [rows][ppr])
   for (int r = r0; r < r1; ++r)
     for (int p = tid; p < ppr; p += nthr) mine[(int64_t)r * ppr + p] = x[(int64_t)r * xs + p];
-  bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
+  bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad, kP2PKindFusedNorm);
   // 2. the rows of this block that I own: sum over the ranks in rank order, rounded -> my result area
   {
     U4* res = mine + area_packs;
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(1024) void p2p_all_reduce_add_rmsnorm_kernel(P2PPee
       }
     }
   }
-  bad = p2p_barrier(peers, rank, world, 1, true, spin_limit, bad);
+  bad = p2p_barrier(peers, rank, world, 1, true, spin_limit, bad, kP2PKindFusedNorm);
   // 3. gather this block's rows from their owners (all loads first), then finish them together
   __shared__ float lds_ss[kFusedRows][16];
   U4 sum[kFusedRows], resq[kFusedRows];
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(1024) void p2p_all_reduce_add_rmsnorm_kernel(P2PPee
       x[(int64_t)(r0 + k) * xs + tid] = bad ? p2p_poison() : pack8f<T>(y);
     }
   }
-  bad = p2p_barrier(peers, rank, world, 2, false, spin_limit, bad);  // nobody refills its areas while a peer still reads
+  bad = p2p_barrier(peers, rank, world, 2, false, spin_limit, bad, kP2PKindFusedNorm);  // nobody refills its areas while a peer still reads
   if (bad && has)
     for (int r = r0; r < r1; ++r) {
       x[(int64_t)r * xs + tid] = p2p_poison();
@@ -309,12 +317,12 @@ __global__ __launch_bounds__(kP2PThreads) void p2p_all_gather_kernel(P2PPeers pe
   int64_t lo, hi;
   block_slice(packs, lo, hi);
   for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) mine[i] = src[i];
-  bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad);
+  bad = p2p_barrier(peers, rank, world, 0, true, spin_limit, bad, kP2PKindGather);
   for (int r = 0; r < world; ++r) {
     const U4* from = reinterpret_cast<const U4*>(peers.base[r] + kP2PHeaderBytes);
     for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) dst[(int64_t)r * packs + i] = bad ? p2p_poison() : from[i];
   }
-  bad = p2p_barrier(peers, rank, world, 1, false, spin_limit, bad);
+  bad = p2p_barrier(peers, rank, world, 1, false, spin_limit, bad, kP2PKindGather);
   if (bad)
     for (int r = 0; r < world; ++r)
       for (int64_t i = lo + threadIdx.x; i < hi; i += kP2PThreads) dst[(int64_t)r * packs + i] = p2p_poison();

@@ -18,6 +18,10 @@
 //     stream the next segment's first two steps.
 //   * work split as in gemm_m256.hip: `full` tiles whole, the rest cut into `tail_split` k-slices spread over all
 //     workgroups (fp32 slabs, added in slice order by a second kernel or by the consumer of the projection).
+//   * tried in round 4 and dropped (profiles/r04a_g3_store_policy_and_loader_roles.json, same-box, bit-identical outputs):
+//     sc1 (write-through) or nt slab stores -- 32.1 -> 38.8 / 36.6 us (qkv), 25.2 -> 34.7 / 31.9 (o), and the pair with the
+//     slab-consuming norm loses as much; two loaders issuing only x pieces and two only w pieces instead of a quarter of both
+//     each -- within 0.5 us everywhere (the x and w terms add per CU whichever wave issues them).
 //   * EPI_SILU: the weight is the gate_up matrix with rows interleaved in blocks of 32 (tile t of 128 rows =
 //     gate[64t .. +32), up[64t .. +32), gate[64t+32 .. +32), up[64t+32 .. +32)): a matrix wave then holds gate and
 //     up of the same output column in the same lane / register slot, and the epilogue writes
@@ -35,7 +39,6 @@ typedef __attribute__((ext_vector_type(16))) float g3_f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 g3_bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 g3_f16x8;
 typedef __attribute__((address_space(3))) void* g3_lds_t;
-typedef uint32_t g3_u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
 __device__ __forceinline__ g3_f32x16 g3_mfma(const U4& a, const U4& b, g3_f32x16 c) {
@@ -59,17 +62,9 @@ constexpr int kG3LdsBytes = kG3Stages * kG3Stage;  // 144 KB
 
 enum { G3_EPI_OUT = 0, G3_EPI_SILU = 1 };
 
-// DMA pieces per step of one loader wave: x pieces, w pieces, loader waves per role
-template <bool SPLIT>
-struct G3Loaders {
-  static constexpr int kNX = SPLIT ? 16 : 8, kNW = SPLIT ? 8 : 4, kNL = SPLIT ? 2 : 4;
-};
-
 // ABL (diagnosis): 1 = no x loads, 2 = no compute, 4 = no w loads, 8 = no epilogue stores.  WPOL = cache policy bits of the weight DMA
-// (0 default, 2 = nt).  SPOL = cache policy bits of the k-slice slab stores (0 plain, 16 = sc1 write-through, 2 = nt).
-// SPLITLD: loader waves 4-5 issue only the x pieces, waves 6-7 only the w pieces (the L2-hit stream and the HBM stream in
-// separate in-order wave queues) instead of every loader issuing a quarter of both.
-template <typename T, int EPI, int WPOL, int ABL, int SPOL = 0, bool SPLITLD = false>
+// (0 default, 2 = nt).
+template <typename T, int EPI, int WPOL, int ABL>
 __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
     uint16_t* __restrict__ out, float* __restrict__ part, const uint16_t* __restrict__ x,
     const uint16_t* __restrict__ w, int M, int nsteps, int64_t ldx, int64_t ldw, int64_t ldo, int tiles, int full,
@@ -84,23 +79,16 @@ __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
     // =============================== loader wave ===============================
     const int L = wv - 4;
     const int drow = lane >> 3, dchunk = lane & 7;
-    // piece p of the x tile = rows [8 p, 8 p + 8) (32 pieces), of the w tile likewise (16 pieces).  Default: loader L takes
-    // x pieces 4 i + L (i < 8) and w pieces 4 i + L (i < 4).  SPLITLD: loaders 0, 1 take x pieces 2 i + L (i < 16), loaders
-    // 2, 3 take w pieces 2 i + (L - 2) (i < 8).
-    // (hipcc / ROCm 7.2: a local array whose BOUND depends on a template parameter makes the host pass silently drop the
-    // kernel's launch stub -- the library then fails to load with an undefined __device_stub__ symbol.  Fixed bounds below.)
-    constexpr int kNX = G3Loaders<SPLITLD>::kNX, kNW = G3Loaders<SPLITLD>::kNW, kNL = G3Loaders<SPLITLD>::kNL;
-    const bool xrole = !SPLITLD || L < 2, wrole = !SPLITLD || L >= 2;
-    const int LL = SPLITLD ? (L & 1) : L;
-    int xvo[16], wvo[8];  // (fixed bounds; only the first kNX / kNW entries exist after unrolling)
+    // piece p of the x tile = rows [8 p, 8 p + 8): this loader takes p = 4 i + L (i < 8); of the w tile p = 4 i + L (i < 4)
+    int xvo[8], wvo[4];
 #pragma unroll
-    for (int i = 0; i < kNX; ++i) {
-      const int row = (kNL * i + LL) * 8 + drow;
+    for (int i = 0; i < 8; ++i) {
+      const int row = (4 * i + L) * 8 + drow;
       xvo[i] = min(row, M - 1) * (int)ldx * 2 + ((dchunk ^ ((row >> 1) & 7)) * 16);
     }
 #pragma unroll
-    for (int i = 0; i < kNW; ++i) {
-      const int row = (kNL * i + LL) * 8 + drow;
+    for (int i = 0; i < 4; ++i) {
+      const int row = (4 * i + L) * 8 + drow;
       wvo[i] = row * (int)ldw * 2 + ((dchunk ^ ((row >> 1) & 7)) * 16);
     }
     const __amdgpu_buffer_rsrc_t xr =
@@ -115,18 +103,14 @@ __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
       total += (int)((int64_t)(slice + 1) * nsteps / tail_split) - (int)((int64_t)slice * nsteps / tail_split);
     }
     total = sgpr(total);
-    static_assert(!SPLITLD || ABL == 0, "the split-loader form has no ablations");
-    constexpr int kPer = ((ABL & 1) ? 0 : 8) + ((ABL & 4) ? 0 : 4);  // DMA instructions per step and loader (default roles)
+    constexpr int kPer = ((ABL & 1) ? 0 : 8) + ((ABL & 4) ? 0 : 4);  // DMA instructions per step and loader
     // Iteration i: [i >= 2: step i - 2 has landed (step i - 1 may stay in flight); barrier B_{i-2}: stage (i - 2) % 3 is
     // visible to the matrix waves and stage i % 3 (step i - 3) is free]  then  [i < total: issue step i into stage i % 3].
     int seg = 0, cstep = 0, cend = 0, ctile = 0, stage = 0;  // issue cursor (all wave-uniform)
     for (int i = 0; i < total + 2; ++i) {
       if (i >= 2) {
         if (i <= total) {
-          if constexpr (SPLITLD) {
-            if (xrole) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          } else if constexpr (kPer == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          if constexpr (kPer == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
           else if constexpr (kPer == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           else if constexpr (kPer == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -152,37 +136,23 @@ __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
             const_cast<uint16_t*>(w) + (int64_t)ctile * kG3TileN * ldw, (short)0, -1, 0x00020000);
         const int kb = cstep * (kG3StepK * 2);
         unsigned char* sb = smem + stage * kG3Stage;
-        if constexpr (SPLITLD) {
-          if (xrole) {
 #pragma unroll
-            for (int q = 0; q < kNX; ++q)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (g3_lds_t)(sb + (kNL * q + LL) * 1024), 16, xvo[q], kb, 0, 0);
-          } else {
-#pragma unroll
-            for (int q = 0; q < kNW; ++q)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (g3_lds_t)(sb + kG3XBytes + (kNL * q + LL) * 1024), 16, wvo[q],
-                                                       kb, 0, WPOL);
+        for (int q = 0; q < 4; ++q) {
+          // order x, x, w: the short-latency L2 hits and the HBM stream interleaved
+          if (!(ABL & 1)) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (g3_lds_t)(sb + (4 * (2 * q) + L) * 1024), 16, xvo[2 * q], kb,
+                                                     0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (g3_lds_t)(sb + (4 * (2 * q + 1) + L) * 1024), 16,
+                                                     xvo[2 * q + 1], kb, 0, 0);
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            // order x, x, w: the short-latency L2 hits and the HBM stream interleaved
-            if (!(ABL & 1)) {
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (g3_lds_t)(sb + (4 * (2 * q) + L) * 1024), 16, xvo[2 * q], kb,
-                                                       0, 0);
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (g3_lds_t)(sb + (4 * (2 * q + 1) + L) * 1024), 16,
-                                                       xvo[2 * q + 1], kb, 0, 0);
-            }
-            if (!(ABL & 4))
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (g3_lds_t)(sb + kG3XBytes + (4 * q + L) * 1024), 16, wvo[q],
-                                                       kb, 0, WPOL);
-          }
+          if (!(ABL & 4))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (g3_lds_t)(sb + kG3XBytes + (4 * q + L) * 1024), 16, wvo[q],
+                                                     kb, 0, WPOL);
         }
         ++cstep;
         stage = stage == 2 ? 0 : stage + 1;
       }
     }
-    (void)wrole;
     return;
   }
 
@@ -241,13 +211,11 @@ __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
       // diagnosis: no stores (the comparison keeps the accumulators alive)
     } else if (partial) {
       const int64_t col = (int64_t)(tile - full) * kG3TileN + ni * 64 + 4 * h;
-      const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(part, (short)0, -1, 0x00020000);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int m = mi * 128 + b * 32 + j;
         if (m < M) {
-          const int64_t e0 = ((int64_t)slice * M + m) * ld_part + col;
-          float* dst = part + e0;
+          float* dst = part + ((int64_t)slice * M + m) * ld_part + col;
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -255,11 +223,7 @@ __global__ __launch_bounds__(kG3Threads) void g3_gemm_kernel(
               float4 v;
               v.x = acc[b][nb][4 * g4 + 0]; v.y = acc[b][nb][4 * g4 + 1];
               v.z = acc[b][nb][4 * g4 + 2]; v.w = acc[b][nb][4 * g4 + 3];
-              if constexpr (SPOL == 0)
-                *reinterpret_cast<float4*>(dst + nb * 32 + 8 * g4) = v;
-              else  // byte offsets < 2^31: the workspace size is checked at launch
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g3_u32x4, v), pr,
-                                                       (int)((e0 + nb * 32 + 8 * g4) * 4), 0, SPOL);
+              *reinterpret_cast<float4*>(dst + nb * 32 + 8 * g4) = v;
             }
         }
       }
@@ -373,9 +337,6 @@ static int launch_g3(uint16_t* out, float* part, const uint16_t* x, const uint16
   const int64_t width = (int64_t)(tiles - full) * kG3TileN;
   const bool silu = flags & MSGL_G3_SILU, skip_reduce = flags & MSGL_G3_SLABS_ONLY;
   const int variant = (flags >> 8) & 0xff;  // diagnosis: bit 0 = nt weight stream off, bits 1-3 = ablation (x, compute, w)
-#define MSGL_G3X(SP, SL)                                                                                              \
-  g3_gemm_kernel<T, G3_EPI_OUT, 2, 0, SP, SL><<<dim3((unsigned)grid), dim3(kG3Threads), 0, s>>>(                      \
-      out, part, x, w, M, nsteps, ldx, ldw, ldo, tiles, full, tail_split, width)
 #define MSGL_G3(E, P, A)                                                                                         \
   g3_gemm_kernel<T, E, P, A><<<dim3((unsigned)grid), dim3(kG3Threads), 0, s>>>(out, part, x, w, M, nsteps, ldx, \
                                                                                  ldw, ldo, tiles, full, tail_split, width)
@@ -392,15 +353,10 @@ static int launch_g3(uint16_t* out, float* part, const uint16_t* x, const uint16
       case 12: MSGL_G3(G3_EPI_OUT, 2, 6); break;  // x re-reads only
       case 10: MSGL_G3(G3_EPI_OUT, 2, 5); break;  // compute only
       case 16: MSGL_G3(G3_EPI_OUT, 2, 8); break;  // no epilogue stores
-      case 32: MSGL_G3X(16, false); break;        // slab stores sc1 (write-through)
-      case 33: MSGL_G3X(2, false); break;         // slab stores nt
-      case 64: MSGL_G3X(0, true); break;          // split loader roles
-      case 96: MSGL_G3X(16, true); break;         // split loader roles + sc1 slab stores
       default: set_error("g3_gemm_nt: unknown variant %d", variant); return MSGL_EINVAL;
     }
   }
 #undef MSGL_G3
-#undef MSGL_G3X
   if (tail_split > 1 && width > 0 && !skip_reduce) {
     if (silu) {
       const int64_t threads = (int64_t)M * (width / 16);
@@ -442,8 +398,8 @@ extern "C" int msgl_g3_gemm_nt(void* out, const void* x, const void* w, int M, i
   MSGL_REQUIRE(aligned16(x) && aligned16(w) && (slabs_only || aligned16(out)), "g3_gemm_nt: pointers must be 16-byte aligned");
   const int64_t need = msgl_m256_gemm_workspace_bytes(M, N, full, tail_split);
   if (need > 0)
-    MSGL_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= need && need < (1ll << 31),
-                 "g3_gemm_nt: plan needs %lld workspace bytes (below 2 GiB)", (long long)need);
+    MSGL_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= need, "g3_gemm_nt: plan needs %lld workspace bytes",
+                 (long long)need);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   if (dtype == MSGL_BF16)

@@ -3,6 +3,7 @@ error behaviour, implemented on the gfx950 C-ABI instead of tvm-ffi JIT modules.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Literal, Optional, Tuple
 
 import torch
@@ -109,6 +110,8 @@ class P2PCommunicator:
         try:
             _lib.check(self._lib.msgl_p2p_open(self._handle, b"".join(h[0] for h in handles)), "p2p_open")
             _lib.check(self._lib.msgl_p2p_configure(self._handle, one_shot_max_bytes, blocks), "p2p_configure")
+            if os.environ.get("MSGL_P2P_SPIN_LIMIT"):  # diagnostics: fail fast instead of after tens of seconds
+                _lib.check(self._lib.msgl_p2p_set_spin_limit(self._handle, int(os.environ["MSGL_P2P_SPIN_LIMIT"])), "p2p_set_spin_limit")
         except Exception as e:  # noqa: BLE001
             err = f"rank {rank}: {e}"
         errs = [None] * world_size
@@ -149,7 +152,7 @@ class P2PCommunicator:
                 if not torch.equal(dst, want):
                     problems.append("all-gather: wrong contents")
             if self.error():
-                problems.append(f"barrier phase {self.error() - 1} timed out")
+                problems.append(self.describe_error(self.error()))
         except Exception as e:  # noqa: BLE001
             problems.append(f"{type(e).__name__}: {e}")
         mine = f"rank {self.rank}: " + "; ".join(problems) if problems else None
@@ -196,7 +199,7 @@ class P2PCommunicator:
         return True
 
     def error(self) -> int:
-        """0, or 1 + the barrier phase that timed out (sticky; synchronises the device)."""
+        """0, or the sticky error word of a barrier that timed out (describe_error decodes it; synchronises the device)."""
         return int(self._lib.msgl_p2p_error(self._handle))
 
     def set_spin_limit(self, spins: int) -> None:
@@ -226,9 +229,18 @@ class P2PCommunicator:
                 self._err_event = torch.cuda.Event()
                 self._err_event.record()
         if e:
-            raise _lib.MsglError(
-                f"peer-to-peer collective: rank {self.rank} of {self.world_size} gave up waiting for a peer at barrier "
-                f"phase {e - 1} (spin limit reached); outputs of that and every later collective are NaN-poisoned")
+            raise _lib.MsglError(self.describe_error(e))
+
+    def describe_error(self, e: int) -> str:
+        """The sticky error word in words (layout: csrc/comm_p2p.hip, `Error word`)."""
+        phase, kind, block, peer, told = (e & 15) - 1, (e >> 4) & 15, (e >> 8) & 255, (e >> 16) & 15, bool(e & (1 << 20))
+        what = {1: "one-shot all-reduce", 2: "two-shot all-reduce", 3: "fused all-reduce + add + RMSNorm", 4: "all-gather"}.get(kind, "collective")
+        if told:
+            return (f"peer-to-peer collective: rank {peer} gave up waiting for a peer in a {what} (barrier phase {phase}, block "
+                    f"{block}) and told rank {self.rank} of {self.world_size}; outputs of every later collective are NaN-poisoned")
+        return (f"peer-to-peer collective: rank {self.rank} of {self.world_size} gave up waiting for a peer (rank {peer}) in a {what} "
+                f"at barrier phase {phase}, block {block} (spin limit reached); outputs of that and every later collective are "
+                "NaN-poisoned")
 
     def get_buffer(self) -> int:
         return int(self._lib.msgl_p2p_get_buffer(self._handle) or 0)

@@ -25,47 +25,80 @@ import torch
 from . import ops
 
 
+class StepBench:
+    """A synthetic full decode batch (bs requests of up to 2 * mean_context tokens in contiguous pool slots; K/V contents are
+    left as they are: timing does not depend on them) replayed through the host's captured decode graph.  `ok` is False --
+    and nothing was touched -- when the KV pool or the page table cannot hold it.  close() restores the page-table rows it
+    borrowed."""
+
+    def __init__(self, *, bs: int, page_table: torch.Tensor, page_size: int, num_pages: int, row_len: int,
+                 device: torch.device, Req: Any, Batch: Any, prepare_metadata: Callable[[Any], None],
+                 capture: Callable[[], None], replay: Callable[[Any], Any], forward_ctx: Callable[[Any], Any],
+                 mean_context: int = 900) -> None:
+        self.capture, self.replay, self.forward_ctx = capture, replay, forward_ctx
+        self.page_table, self.bs = page_table, bs
+        L = -(-(2 * mean_context) // page_size) * page_size  # slots per request row (page multiple)
+        L = min(L, row_len // page_size * page_size, page_table.shape[1] // page_size * page_size)
+        self.L = L
+        self.ok = not (L < 64 or bs * L > num_pages * page_size or bs > page_table.shape[0])
+        self.saved = None
+        if not self.ok:
+            return
+        self.saved = page_table[:bs, :L].clone()
+        page_table[:bs, :L] = (torch.arange(bs, device=device, dtype=torch.int32)[:, None] * L
+                               + torch.arange(L, device=device, dtype=torch.int32)[None, :])
+        lens = [max(16, min(L - 1, int(mean_context * (0.25 + 1.5 * ((i * 37) % 101) / 100.0)))) for i in range(bs)]
+        reqs = [Req(input_ids=torch.zeros(n + 1, dtype=torch.int32), table_idx=i, cached_len=n, output_len=1 << 20, uid=-2 - i,
+                    **_req_extras(Req)) for i, n in enumerate(lens)]
+        batch = Batch(reqs=reqs, phase="decode")
+        batch.padded_reqs = reqs
+        batch.input_ids = torch.zeros(bs, dtype=torch.int32, device=device)
+        batch.positions = torch.tensor(lens, dtype=torch.int32, device=device)
+        batch.out_loc = page_table[torch.arange(bs, device=device), batch.positions.long()].contiguous()
+        prepare_metadata(batch)
+        self.batch = batch
+
+    def measure(self, replays: int = 20) -> float:
+        """Re-capture with the plans / kernel choices in force, then the MEDIAN (ms) of `replays` individually timed
+        replays (one event pair each: a clock ramp or a stray host stall moves single samples, not the median)."""
+        self.capture()
+        batch = self.batch
+        with self.forward_ctx(batch):
+            self.replay(batch)
+            self.replay(batch)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(replays + 1)]
+            evs[0].record()
+            for i in range(replays):
+                self.replay(batch)
+                evs[i + 1].record()
+            evs[-1].synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+        return ts[len(ts) // 2]
+
+    def close(self) -> None:
+        if self.saved is not None:
+            self.page_table[: self.bs, : self.L] = self.saved
+            self.saved = None
+
+
 def refine_plans_in_graph(*, bs: int, page_table: torch.Tensor, page_size: int, num_pages: int, row_len: int,
                           device: torch.device, Req: Any, Batch: Any, prepare_metadata: Callable[[Any], None],
                           capture: Callable[[], None], replay: Callable[[Any], Any], forward_ctx: Callable[[Any], Any],
                           mean_context: int = 900, replays: int = 20, margin: float = 0.005) -> List[dict]:
     """Returns one dict per refined projection: step times (ms) per candidate, the one kept, whether it changed.
     Nothing happens (empty list) when no shape of batch `bs` has more than one candidate or the KV pool cannot hold the
-    synthetic batch (bs requests of up to 2 * mean_context tokens in contiguous slots; K/V contents are left as they
-    are: timing does not depend on them).  The page-table rows it borrows are restored."""
+    synthetic batch (StepBench).  The page-table rows it borrows are restored."""
     keys = [k for k in ops._CANDIDATES if k[1] == bs and len(ops._CANDIDATES[k]["cands"]) > 1]
-    L = -(-(2 * mean_context) // page_size) * page_size  # slots per request row (page multiple)
-    L = min(L, row_len // page_size * page_size, page_table.shape[1] // page_size * page_size)
-    if not keys or L < 64 or bs * L > num_pages * page_size or bs > page_table.shape[0]:
+    if not keys:
         return []
-    saved = page_table[:bs, :L].clone()
-    page_table[:bs, :L] = (torch.arange(bs, device=device, dtype=torch.int32)[:, None] * L
-                           + torch.arange(L, device=device, dtype=torch.int32)[None, :])
-    lens = [max(16, min(L - 1, int(mean_context * (0.25 + 1.5 * ((i * 37) % 101) / 100.0)))) for i in range(bs)]
-    reqs = [Req(input_ids=torch.zeros(n + 1, dtype=torch.int32), table_idx=i, cached_len=n, output_len=1 << 20, uid=-2 - i,
-                **_req_extras(Req)) for i, n in enumerate(lens)]
-    batch = Batch(reqs=reqs, phase="decode")
-    batch.padded_reqs = reqs
-    batch.input_ids = torch.zeros(bs, dtype=torch.int32, device=device)
-    batch.positions = torch.tensor(lens, dtype=torch.int32, device=device)
-    batch.out_loc = page_table[torch.arange(bs, device=device), batch.positions.long()].contiguous()
-    prepare_metadata(batch)
+    sb = StepBench(bs=bs, page_table=page_table, page_size=page_size, num_pages=num_pages, row_len=row_len, device=device,
+                   Req=Req, Batch=Batch, prepare_metadata=prepare_metadata, capture=capture, replay=replay,
+                   forward_ctx=forward_ctx, mean_context=mean_context)
+    if not sb.ok:
+        return []
 
     def measure() -> float:
-        """Re-capture with the plans in force, then the MEDIAN of `replays` individually timed replays (one event pair
-        each: a clock ramp or a stray host stall moves single samples, not the median)."""
-        capture()
-        with forward_ctx(batch):
-            replay(batch)
-            replay(batch)
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(replays + 1)]
-            evs[0].record()
-            for i in range(replays):
-                replay(batch)
-                evs[i + 1].record()
-            evs[-1].synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
-        return ts[len(ts) // 2]
+        return sb.measure(replays)
 
     def forget_pending() -> None:
         # a candidate that failed mid-forward may have left a deferred reduce / all-reduce registered: the next capture
@@ -114,9 +147,9 @@ def refine_plans_in_graph(*, bs: int, page_table: torch.Tensor, page_size: int, 
                     tried["confirm"] = f"{type(e).__name__}: {e}"[:160]
             report.append(dict(name=info["name"], M=key[1], N=key[2], K=key[3], step_ms=tried, replays=replays, margin=margin,
                                chosen=ops.current_candidate(key), changed=accepted))
-        capture()  # the graph that stays = the plans that stay
+        sb.capture()  # the graph that stays = the plans that stay
     finally:
-        page_table[:bs, :L] = saved
+        sb.close()
     return report
 
 

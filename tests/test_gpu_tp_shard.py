@@ -105,7 +105,10 @@ def test_rank_shard_full_decode_batch_with_tuned_plans_vs_oracle(dev, preset, tp
         used = torch.cat([f["out_loc"][: sum(d - c for d, c in zip(f["device_lens"][: f["size"]], f["cached_lens"][: f["size"]]))]
                           for f in rec]).long().unique()
         for li in (0, layers - 1):
-            torch.testing.assert_close(dev_k[li][used].float(), kp[li][used].float(), atol=6e-2, rtol=6e-2)
+            # K rows: a few elements differ by one or two bf16 ulp (the qkv GEMM's summation order); without qk-norm (llama)
+            # |K| reaches ~8, where one ulp is 6.2e-2: the bound scales with the magnitude
+            want_k = kp[li][used].float()
+            torch.testing.assert_close(dev_k[li][used].float(), want_k, atol=max(6e-2, 2.0 ** -6 * float(want_k.abs().max())), rtol=6e-2)
     finally:
         if eng is not None:
             eng.shutdown()
