@@ -128,15 +128,16 @@ def gemm_traffic_over_algorithmic():
     norm / qk pass and SiLU.mul; committed rocprofv3 PMC passes of tools/pmc_gemm.py, k-sliced plans) over its algorithmic
     bytes (weights + activations in and out).  (ratio, source) or (None, None)."""
     try:
-        f = json.loads((ROOT / "profiles" / "r03_pmc_gemm_FETCH_SIZE.json").read_text())
-        w = json.loads((ROOT / "profiles" / "r03_pmc_gemm_WRITE_SIZE.json").read_text())
+        fp = sorted((ROOT / "profiles").glob("r*_pmc_gemm_FETCH_SIZE.json"))[-1]  # the newest round's passes
+        wp = fp.with_name(fp.name.replace("FETCH_SIZE", "WRITE_SIZE"))
+        f, w = json.loads(fp.read_text()), json.loads(wp.read_text())
     except Exception:
         return None, None
     ops_ = [k for k in f["per_launch"] if not k.startswith("gate_up g3") and not k.startswith("tail reduce")]
     moved = sum(2.0 * f["per_launch"][k]["FETCH_SIZE"] + w["per_launch"][k]["WRITE_SIZE"] for k in ops_) * 1024.0
     man = f["manifest"]
     algo = sum(man["algorithmic_bytes"].values()) + 2 * man["norm_algorithmic_bytes"] + man["silu_algorithmic_bytes"]
-    return moved / algo, "profiles/r03_pmc_gemm_FETCH_SIZE.json + r03_pmc_gemm_WRITE_SIZE.json"
+    return moved / algo, f"profiles/{fp.name} + {wp.name}"
 
 
 def measure_prefill_attention(device, hq: int, hkv: int, budget: int = 16384):

@@ -40,6 +40,7 @@ DIMS = {
     "tiny": (2, 256, 10, 2, 128, 512, 1024, False),
     "qwen3-0.6b": (28, 1024, 16, 8, 128, 3072, 151936, True),
     "qwen3-14b": (40, 5120, 40, 8, 128, 17408, 151936, False),
+    "qwen3-32b": (64, 5120, 64, 8, 128, 25600, 151936, False),
 }
 
 
@@ -110,6 +111,24 @@ def write_model_dir(path: Path, model: str, *, weights: bool, seed: int = 42, ma
         st = {k: v.contiguous().cpu() for k, v in seeded_hf_state(model, seed, device).items()}
         save_file(st, str(path / "model.safetensors"))
     return path
+
+
+def synth_qwen_trace(n: int, rate_per_s: float, seed: int = 42):
+    """A stand-in for the Qwen usage trace the reference's online benchmark downloads (benchmark/online/bench_qwen.py:21,
+    fields timestamp / input_length / output_length, client.py:413-421): no network here, so Poisson arrivals at
+    `rate_per_s` with log-normal lengths (input median ~900 tokens, sigma 1.0, clipped to [16, 6000]; output median ~200,
+    sigma 0.8, clipped to [8, 1000]).  NOT the real trace: a workload of the same kind, stated as such wherever reported."""
+    import math
+    import random
+
+    rnd = random.Random(seed)
+    t, out = 0.0, []
+    for _ in range(n):
+        t += rnd.expovariate(rate_per_s)
+        inp = int(min(6000, max(16, math.exp(rnd.gauss(math.log(900), 1.0)))))
+        outl = int(min(1000, max(8, math.exp(rnd.gauss(math.log(200), 0.8)))))
+        out.append(dict(t=round(t, 4), input_length=inp, output_length=outl))
+    return out
 
 
 # ------------------------------------------------------------------------------ worker process

@@ -91,6 +91,86 @@ def replay_through_repo_engine(spec, forwards, ref_engine, tp_rank, tp_size, rec
     return out
 
 
+def trace_replay(LLM, model_dir, kw, spec, tp_args):
+    """BASELINE config 4 as a scheduler-level replay (benchmark/online/bench_qwen.py:37-51, P/benchmark/client.py:284-384):
+    requests ARRIVE at the trace's timestamps, prompts are prefixes of one token sequence (the benchmark's `dummy=True`
+    mode, client.py:428-431: the radix cache sees shared prefixes), every request generates exactly `output_length` tokens
+    (ignore_eos), and per-token arrival times give TTFT / TPOT / E2E with the percentile rule of process_benchmark_results.
+    The HTTP front end, tokenizer workers and ZMQ hops of the online server are NOT in the loop (out of scope, SURVEY.md
+    section 8): the clock runs from a request's scheduled arrival to the scheduler handing its tokens to offline_send_result."""
+    import time
+
+    import torch
+    from minisgl.core import SamplingParams
+    from minisgl.llm.llm import RequestAllFinished
+    from minisgl.message import UserMsg
+
+    trace = sorted(spec["trace"], key=lambda r: r["t"])
+    scale = float(spec.get("trace_scale", 1.0))
+    g = torch.Generator().manual_seed(7)
+    base = torch.randint(0, 10000, (max(r["input_length"] for r in trace) + 1,), generator=g, dtype=torch.int32)
+
+    class TraceLLM(LLM):
+        tracing = False
+
+        def begin(self):
+            self.nxt, self.t0, self.tics, self.open_, self.tracing = 0, time.perf_counter(), {}, 0, True
+
+        def offline_receive_msg(self, blocking=False):
+            if not self.tracing:  # the warm-up generate()
+                return super().offline_receive_msg(blocking)
+            while True:
+                now = time.perf_counter() - self.t0
+                out = []
+                while self.nxt < len(trace) and trace[self.nxt]["t"] * scale <= now and len(out) < 64:
+                    r = trace[self.nxt]
+                    uid = self.nxt
+                    self.tics[uid] = [r["t"] * scale]
+                    out.append(UserMsg(uid=uid, input_ids=base[: r["input_length"]].clone(),
+                                       sampling_params=SamplingParams(temperature=0.0, max_tokens=int(r["output_length"]), ignore_eos=True)))
+                    self.nxt += 1
+                    self.open_ += 1
+                if out or not blocking:
+                    return out
+                if self.nxt >= len(trace):
+                    raise RequestAllFinished()
+                time.sleep(max(0.0, min(0.005, trace[self.nxt]["t"] * scale - now)))
+
+        def offline_send_result(self, reply):
+            if not self.tracing:
+                return super().offline_send_result(reply)
+            t = time.perf_counter() - self.t0
+            for msg in reply:
+                self.tics[msg.uid].append(t)
+                if msg.finished:
+                    self.open_ -= 1
+
+    llm = TraceLLM(model_dir, *tp_args, **kw)
+    # one untimed warm-up request (library kernels for the shapes, allocator pools), as the offline benchmark does
+    llm.generate([[1, 2, 3, 4, 5, 6, 7, 8]], SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True))
+    llm.begin()
+    try:
+        llm.run_forever()
+    except RequestAllFinished:
+        pass
+    torch.cuda.synchronize()
+    tics = [llm.tics[i] for i in range(len(trace))]
+    first = sorted(t[1] - t[0] for t in tics if len(t) > 1)
+    accum = sorted(d for t in tics for d in (b - a for a, b in zip(t[1:-1], t[2:])))
+    e2e = sorted(t[-1] - t[0] for t in tics)
+
+    def stats(v, k=1.0):
+        return dict(avg=k * sum(v) / len(v), p50=k * v[int(len(v) * 0.5)], p90=k * v[int(len(v) * 0.9)], p99=k * v[int(len(v) * 0.99)],
+                    max=k * v[-1]) if v else None
+
+    dur = max(t[-1] for t in tics) - min(t[0] for t in tics)
+    ntok = sum(len(t) - 1 for t in tics)
+    complete = all(len(t) - 1 == r["output_length"] for t, r in zip(tics, trace))
+    return llm, dict(requests=len(trace), tokens=ntok, complete=complete, duration_s=dur, throughput_tok_s=ntok / dur,
+                     req_per_s=len(trace) / dur, ttft_ms=stats(first, 1e3), tpot_ms=stats(accum, 1e3), e2e_s=stats(e2e),
+                     input_tokens=sum(r["input_length"] for r in trace), trace_scale=scale)
+
+
 def gated_mlp_checks(plugin, engine, model_dir):
     """a GatedMLP whose gate_up rows the plugin interleaved must never take the reference forward on
     them.  Inputs the fused path used to hand to the reference forward (3-D, non-contiguous), the un-permute helpers, and
@@ -189,6 +269,24 @@ def main() -> None:
     kw.setdefault("attention_backend", "hip")
     kw["use_dummy_weight"] = spec.get("weights", "seeded") == "dummy"
     t0 = time.perf_counter()
+    if spec.get("trace"):
+        llm, result = trace_replay(LLM, model_dir, kw, spec, ())
+        cm = llm.cache_manager
+        rec = dict(spec={k: v for k, v in spec.items() if k != "trace"}, trace_replay=result, init_and_run_s=time.perf_counter() - t0,
+                   gemm_report=plugin.gemm_report(), backend=type(llm.engine.attn_backend).__name__,
+                   prefix_cache=type(cm.prefix_cache).__name__, graph_bs=list(llm.engine.graph_runner.graph_bs_list),
+                   num_pages=llm.engine.num_pages, device=torch.cuda.get_device_name(0))
+        try:
+            cm.check_integrity()
+            rec["integrity"] = "ok"
+        except Exception as e:
+            rec["integrity"] = f"{type(e).__name__}: {e}"
+        torch.save(rec, out_path)
+        try:
+            llm.shutdown()
+        except Exception as e:
+            print(f"[worker] shutdown: {type(e).__name__}: {e}", file=sys.stderr)
+        return
     if tp_size == 1:
         llm = LLM(model_dir, **kw)
     else:

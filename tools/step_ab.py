@@ -7,7 +7,8 @@ re-captured and replayed, rounds interleaved, median of individually timed repla
 
 knobs:
     decode72      paged decode attention with the split-KV merge folded into the last-arriving piece (msgl_attn_decode_select 72)
-                  instead of the separate merge kernel
+                  instead of the separate merge kernel (round 4: the default at >= 192 requests)
+    decode71      the separate merge kernel forced (what round 3 ran)
     decode1       the streaming (VALU) decode attention kernel
     no_slab_norm  o_proj / down_proj slabs reduced by their own launch instead of by the following norm
     lib_o / lib_qkv / lib_down / lib_gate_up     the library's best solution for that projection instead of the planned kernel
@@ -65,6 +66,7 @@ def main():
 
     knobs = {
         "decode72": (lambda: ops.attn_decode_select(72), lambda: ops.attn_decode_select(0)),
+        "decode71": (lambda: ops.attn_decode_select(71), lambda: ops.attn_decode_select(0)),
         "decode1": (lambda: ops.attn_decode_select(1), lambda: ops.attn_decode_select(0)),
         "no_slab_norm": (lambda: setattr(model_mod, "_SLAB_NORM", False), lambda: setattr(model_mod, "_SLAB_NORM", True)),
     }

@@ -1,0 +1,52 @@
+"""BASELINE config 4 ("Qwen3-32B ..., Qwen-trace 1000-req replay", README online benchmark) as a SCHEDULER-LEVEL replay on
+one MI355X: the REFERENCE's own Scheduler / PrefillManager / radix cache / Engine / GraphRunner (through
+minisgl_plugin.install(), as in tests/test_gpu_reference_driven.py) fed requests at the trace's arrival times; TTFT, TPOT and
+E2E percentiles by the rule of the reference's benchmark client (P/benchmark/client.py:324-384).
+
+    python tools/trace_replay.py [--model qwen3-32b] [--requests 300] [--rate 6.0] [--scale 1.0] [--out gpurun_out/trace_replay.json]
+
+What it is NOT: the HTTP server / tokenizer / ZMQ path (out of scope), the real Qwen trace (no network:
+tests/refdrive.synth_qwen_trace documents the synthetic stand-in), or TP = 4 (one GPU here: Qwen3-32B runs at TP = 1 in
+64 GB of the 288 GB).  Random weights (`use_dummy_weight`): only time is measured.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="qwen3-32b")
+    ap.add_argument("--requests", type=int, default=300)
+    ap.add_argument("--rate", type=float, default=6.0, help="mean arrivals per second of the synthetic trace")
+    ap.add_argument("--scale", type=float, default=1.0, help="timestamps x scale (the reference sweeps 0.4 .. 1.6)")
+    ap.add_argument("--gemm-tune", default="heuristic")
+    ap.add_argument("--out", default="gpurun_out/trace_replay.json")
+    args = ap.parse_args()
+    import refdrive
+
+    trace = refdrive.synth_qwen_trace(args.requests, args.rate)
+    kw = dict(page_size=256, max_running_req=256, cuda_graph_bs=[1, 2, 4, 8, 16, 32, 64, 96, 128, 192, 256], max_seq_len_override=8192,
+              max_extend_tokens=8192, cache_type="radix", memory_ratio=0.9)
+    rec = refdrive.run_worker(dict(model=args.model, weights="dummy", llm_kwargs=kw, gemm_tune=args.gemm_tune, vectorized_glue=True,
+                                   native_radix=True, trace=trace, trace_scale=args.scale, max_position=40960), timeout=1500)
+    r = rec["trace_replay"]
+    out = dict(what="scheduler-level replay of a synthetic Qwen-like trace through the reference's Scheduler on the HIP backend",
+               model=args.model, tp=1, device=rec["device"], backend=rec["backend"], prefix_cache=rec["prefix_cache"],
+               graph_bs=rec["graph_bs"], integrity=rec["integrity"], init_and_run_s=rec["init_and_run_s"],
+               trace=dict(kind="synthetic (tests/refdrive.synth_qwen_trace)", requests=args.requests, rate_per_s=args.rate,
+                          scale=args.scale, input_tokens=r["input_tokens"], output_tokens=r["tokens"]), **r)
+    print(json.dumps({k: out[k] for k in ("model", "requests", "complete", "duration_s", "throughput_tok_s", "ttft_ms", "tpot_ms", "e2e_s")}))
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.out).write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

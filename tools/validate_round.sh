@@ -2,11 +2,11 @@
 # End-of-round validation on the GPU box (run through gpurun from the repo root): GPU parity suite, the driver's bench
 # command, rocprofv3 kernel trace of the same command, PMC traffic passes of the dominant kernel.  Every step is
 # bounded by `timeout`; summaries land in gpurun_out/<tag>_* (copy what is to be judged into profiles/).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-( time timeout 900 python -m pytest tests -m gpu -q -x ) > gpurun_out/${TAG}_pytest.log 2>&1
+( time timeout 1200 python -m pytest tests -m gpu -q -x ) > gpurun_out/${TAG}_pytest.log 2>&1
 tail -4 gpurun_out/${TAG}_pytest.log | cut -c1-200
 ( time timeout 600 python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python - <<PY
@@ -53,7 +53,7 @@ except Exception:
     print(17.8)
 PY
 )
-for cfg in "qwen3-14b 2" "qwen3-14b 4" "qwen3-14b 8" "qwen3-32b 4"; do set -- $cfg; timeout 200 python bench.py --model $1 --rank-shard $2 --tp1-ms $MS --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_rank_shard_$1_tp$2.json; cut -c1-200 gpurun_out/${TAG}_rank_shard_$1_tp$2.json; done
+for cfg in "qwen3-14b 2" "qwen3-14b 4" "qwen3-14b 8" "qwen3-32b 4" "llama-3.1-70b 8"; do set -- $cfg; timeout 200 python bench.py --model $1 --rank-shard $2 --tp1-ms $MS --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_rank_shard_$1_tp$2.json; cut -c1-200 gpurun_out/${TAG}_rank_shard_$1_tp$2.json; done
 bash tools/trace_small_batch.sh ${TAG} 1 > gpurun_out/${TAG}_b1_trace.log 2>&1; head -3 gpurun_out/${TAG}_b1_kernel_breakdown.txt
 # same-box A/B of the decode attention kernels, per-wave clock stamps of the default one, MFMA counters of prefill attention
 cd $R
@@ -81,3 +81,23 @@ except Exception as e:
 PY
 timeout 300 bash tools/pmc_prefill.sh ${TAG} 2 4 > gpurun_out/${TAG}_pmc_prefill.log 2>&1; grep -c "SQ_" gpurun_out/${TAG}_pmc_prefill.txt
 timeout 100 python tools/skinny_silu_bench.py --out gpurun_out/${TAG}_skinny_silu_bench.json 2>&1 | tail -3 | cut -c1-200
+# round 4: the N > 1 path of bench.py end to end through its SELF-LAUNCH (python3 bench.py --gpus N, no torchrun around it), all
+# ranks on this box's one GPU over the peer-to-peer communicator (MSGL_BENCH_SHARE_GPU=1: a code-path check, not a
+# measurement; --gpus 4 also runs the Qwen3-32B TP4 entry); what one CU's memory pipe delivers by source (tools/cu_pipe_probe.hip);
+# kernel choices A/B'd inside the captured step; BASELINE config 4 as a scheduler-level trace replay (Qwen3-32B, TP1 here)
+cd $R
+for N in 2 4; do
+  ( time MSGL_BENCH_SHARE_GPU=1 MSGL_GEMM_TUNE=off timeout 500 python bench.py --gpus $N --steps 3 --warmup 1 ) > gpurun_out/${TAG}_bench_tp${N}_ranks_on_one_gpu_code_path_check.json 2> gpurun_out/${TAG}_bench_tp${N}_share.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open("gpurun_out/${TAG}_bench_tp${N}_ranks_on_one_gpu_code_path_check.json").read().strip().splitlines()[-1])
+    print("self-launched --gpus ${N} on one GPU:", d["launch"], "| ms/step", round(d["ms_per_step"], 1), "|", d["collectives"]["paths"],
+          "| 32B entry:", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in d.get("qwen3_32b_tp4", {}).items() if k in ("ms_per_step", "error")})
+except Exception as e:
+    print("self-launch --gpus ${N}: unreadable:", e)
+PY
+done
+timeout 120 tools/build/cu_pipe_probe > gpurun_out/${TAG}_cu_pipe_probe.txt 2>&1; tail -13 gpurun_out/${TAG}_cu_pipe_probe.txt | cut -c1-200
+timeout 400 python tools/step_ab.py --rounds 3 --knobs decode72 decode71 lib_o lib_gate_up no_slab_norm --out gpurun_out/${TAG}_step_ab.json 2>&1 | tail -2 | cut -c1-600
+timeout 900 python tools/trace_replay.py --model qwen3-32b --requests 300 --rate 6.0 --out gpurun_out/${TAG}_trace_replay_qwen3-32b_tp1.json 2>&1 | tail -2 | cut -c1-700
