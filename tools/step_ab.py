@@ -12,6 +12,7 @@ knobs:
     decode1       the streaming (VALU) decode attention kernel
     no_slab_norm  o_proj / down_proj slabs reduced by their own launch instead of by the following norm
     lib_o / lib_qkv / lib_down / lib_gate_up     the library's best solution for that projection instead of the planned kernel
+    plan:<o|qkv|down|gate_up>:<grid>/<whole tiles>/<k-slices>/<0 m256 | 1 g3>    that full-batch plan instead of the planned kernel
 """
 from __future__ import annotations
 
@@ -73,6 +74,16 @@ def main():
     for name in ("o", "qkv", "down", "gate_up"):
         if name in keys:
             knobs["lib_" + name] = lib_knob(name)
+
+    def plan_knob(spec):  # "plan:<projection>:<grid>/<whole tiles>/<k-slices>/<impl 0 m256 | 1 g3>", e.g. plan:o:256/0/3/1
+        _, name, plan = spec.split(":")
+        key, p4 = keys[name], tuple(int(v) for v in plan.split("/"))
+        snap = ops.snapshot_plan(key)
+        return (lambda: ops.apply_candidate(key, ("hand", p4))), (lambda: ops.restore_search_pick(key, snap))
+
+    for kn in args.knobs:
+        if kn.startswith("plan:"):
+            knobs[kn] = plan_knob(kn)
     res = {"model": args.model, "batch": B, "plans": {n: ops.current_candidate(k) for n, k in keys.items()}, "base_ms": [], "knobs": {}}
     try:
         for rnd in range(args.rounds):
