@@ -199,7 +199,8 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
  * launch must be made under the same choice): 0 = default (matrix-core kernel for slot_run >= 16, streaming kernel
  * otherwise), 1 = streaming kernel only; for timing and diagnosis also 10 w + s = matrix-core kernel held to w waves
  * per SIMD with an s-stage request ring (22, 23, 24, 32), 72 = variant 22 with the in-kernel combine instead of
- * the merge kernel, 92 = variant 22 with the products left out (what the request pattern alone costs), 93 =
+ * the merge kernel (round 4: what the default does for batches of >= 192 requests), 71 = the default variant with the
+ * merge kernel forced, 92 = variant 22 with the products left out (what the request pattern alone costs), 93 =
  * variant 22 leaving clock stamps (msgl_attn_decode_trace).  Also settable by
  * MSGL_DECODE_IMPL before the first call.  Both kernels meet the same tolerance against the oracle. */
 int msgl_attn_decode_select(int impl);

@@ -1145,9 +1145,10 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 72 || impl == 92 || impl == 93 || impl == 94,
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 71 || impl == 72 || impl == 92 || impl == 93 || impl == 94,
                "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
-               "w waves per SIMD and s ring stages)", impl);
+               "w waves per SIMD and s ring stages, 71 / 72 = the default variant with the merge kernel forced / with the "
+               "in-kernel combine forced)", impl);
   g_decode_impl = impl;
   return MSGL_OK;
 }

@@ -75,8 +75,9 @@ def test_p2p_barrier_timeout_poisons_and_raises(dev):
     meanwhile rewritten -- it poisons from its next barrier on and its host raises at its next poll."""
     r0, r1 = launch("absent_rank", 2, timeout=180.0)
     assert r0["two_shot_all_nan"] and r0["one_shot_all_nan"] and r0["gather_all_nan"], r0
-    # same phase / collective kind / block on both sides; the told copy carries bit 20 and the failing rank (0)
-    assert r0["error_word"] != 0 and (r1["error_word"] & 0xffff) == (r0["error_word"] & 0xffff), (r0["error_word"], r1["error_word"])
+    # same phase / collective kind on both sides (the block recorded is whichever block wrote last); the told copy carries
+    # bit 20 and the failing rank (0)
+    assert r0["error_word"] != 0 and (r1["error_word"] & 0xff) == (r0["error_word"] & 0xff), (r0["error_word"], r1["error_word"])
     assert r1["error_word"] & (1 << 20) and (r1["error_word"] >> 16) & 15 == 0 and not r0["error_word"] & (1 << 20)
     assert r1["late_all_nan"] and r1["late_raised"] and "gave up waiting" in r1["late_raised"]
     assert r0["raised"]["sync"] and "gave up waiting" in r0["raised"]["sync"]
