@@ -177,12 +177,14 @@ int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, i
  * min_chunk: smallest slot in tokens (power of two >= 16).  The plan buffer
  * must be 16-byte aligned; plan[0] = pieces, [1] = tokens per slot, [3] = slots.
  * ---------------------------------------------------------------------- */
-/* number of int32 words the plan buffer needs  * Combining the split-KV partial sums: a merge kernel follows the partial kernel.  Alternative kept for measurement
- * (msgl_attn_decode_select(72)): the piece of a request that arrives last (per-(request, kv head) arrival counters at
- * the end of the plan buffer, zeroed by msgl_attn_decode_plan and left at zero by every launch) reads the others'
- * partial sums -- published write-through -- and writes the output itself, in piece order with the merge kernel's
- * arithmetic: same bits, one launch less, but not faster; msgl_attn_decode then WRITES those counters inside `plan`.
+/* Combining the split-KV partial sums.  Batches below 192 requests: a merge kernel follows the partial kernel.  Full
+ * batches (>= 192 requests; round 4, forced by msgl_attn_decode_select(72), forbidden by 71): the piece of a request that
+ * arrives LAST (per-(request, kv head) arrival counters at the end of the plan buffer, zeroed by msgl_attn_decode_plan and
+ * left at zero by every launch) reads the others' partial sums -- published write-through -- and writes the output itself,
+ * in piece order with the merge kernel's arithmetic: same bits, one launch per layer less (worth 45 us per 256-sequence
+ * step inside the captured graph, profiles/r04*_step_ab*.json); msgl_attn_decode then WRITES those counters inside `plan`.
  */
+/* number of int32 words the plan buffer needs */
 int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);
 /* bytes of fp32 workspace for split-KV partials */
 int64_t msgl_attn_decode_workspace_bytes(int capacity, int num_q_heads, int head_dim);
