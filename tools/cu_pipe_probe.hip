@@ -75,6 +75,64 @@ __global__ __launch_bounds__(kThreads) void probe_kernel(const u32x4* __restrict
   if (tid == 0 && lds[0] == 77) sink[0] = 1;
 }
 
+// The weight stream of a 256 x 128 projection tile as csrc/gemm_g3.hip issues it: per 64-k step 128 rows x 128 B, rows
+// `ld` bytes apart (K = 5120: 10240 B), next step = the next 128 B of every row -- against the same bytes laid out
+// contiguously per tile (16 KB per step, steps consecutive).  CHUNK = bytes of one row read per step (128: k-step 64;
+// 256 / 512: what a deeper k-step or a [tile][step] packed layout would give).  Each workgroup streams `rows` x `ld_used`
+// bytes of its own rows; U loads in flight per lane.
+template <int U, int CHUNK>
+__global__ __launch_bounds__(kThreads) void tile_kernel(const unsigned char* __restrict__ w, uint32_t* __restrict__ sink,
+                                                        int64_t ld, int rows, int64_t row_bytes, int64_t tile_stride) {
+  extern __shared__ unsigned char lds[];
+  const int tid = threadIdx.x;
+  constexpr int kLanesPerRow = CHUNK / 16;             // lanes covering one row's chunk
+  constexpr int kRowsPerLoad = kThreads / kLanesPerRow;  // rows one 256-lane load instruction covers
+  const int r0 = tid / kLanesPerRow, c = (tid % kLanesPerRow) * 16;
+  const unsigned char* base = w + (int64_t)blockIdx.x * tile_stride;
+  u32x4 acc = {0, 0, 0, 0};
+  const int loads_per_step = rows / kRowsPerLoad;  // instructions per step
+  const int64_t steps = row_bytes / CHUNK;
+  // flatten (step, load) and keep U in flight
+  const int64_t total = steps * loads_per_step;
+  for (int64_t i = 0; i < total; i += U) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + u < total ? i + u : total - 1;
+      const int64_t st = j / loads_per_step;
+      const int q = (int)(j - st * loads_per_step);
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)(q * kRowsPerLoad + r0) * ld + st * CHUNK + c));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x * kThreads + tid] = acc.x;
+  if (tid == 0 && lds[0] == 77) sink[0] = 1;
+}
+
+template <int CHUNK>
+static float run_tile(int G, const unsigned char* w, int64_t total_bytes, uint32_t* sink, int64_t ld, int rows, int64_t row_bytes,
+                      int64_t tile_stride, int64_t launch_span, int reps, int64_t* cursor) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel<16, CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10));
+  float best = 1e30f;
+  for (int i = 0; i < reps + 1; ++i) {
+    if (*cursor + launch_span > total_bytes) *cursor = 0;
+    const unsigned char* win = w + *cursor;
+    *cursor += launch_span;
+    CHECK(hipEventRecord(e0));
+    tile_kernel<16, CHUNK><<<dim3(G), dim3(kThreads), 100 << 10>>>(win, sink, ld, rows, row_bytes, tile_stride);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (i > 0 && ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
 template <int U>
 static float run(int G, int mode, const u32x4* hbm, int64_t hbm_bytes_total, const u32x4* l2, uint32_t* sink,
                  int64_t hbm_per_block, int64_t l2_bytes, int l2_passes, int reps, int64_t* cursor) {
@@ -134,6 +192,27 @@ int main() {
              hb * G / th / 1e6, tl, lb / tl / 1e3, lb * G / tl / 1e6, tm, th + tl, tm / (th + tl));
       fflush(stdout);
     }
+  }
+  // ---- access pattern of the weight stream (G = 256 workgroups, one 128-row tile of a [N, K = 5120] bf16 matrix each)
+  {
+    const int G = 256, rows = 128;
+    const int64_t K2 = 10240;  // bytes per weight row
+    const int64_t tile_bytes = rows * K2, span = (int64_t)G * tile_bytes;  // 335 MB per launch
+    auto line = [&](const char* what, float us) {
+      printf("%-92s %8.1f us  %6.2f TB/s\n", what, us, (double)span / us / 1e6);
+      fflush(stdout);
+    };
+    printf("\nweight-stream access pattern, 256 workgroups x one 128-row tile (1.31 MB) each, 16 loads in flight per lane:\n");
+    line("row-major [N][K] as gemm_g3 reads it: 128 rows x 128 B per step, rows 10240 B apart",
+         run_tile<128>(G, (const unsigned char*)hbm, hbm_total, sink, K2, rows, K2, tile_bytes, span, 5, &cursor));
+    line("row-major, 256 B of every row per step (k-step 128)",
+         run_tile<256>(G, (const unsigned char*)hbm, hbm_total, sink, K2, rows, K2, tile_bytes, span, 5, &cursor));
+    line("row-major, 512 B of every row per step (k-step 256)",
+         run_tile<512>(G, (const unsigned char*)hbm, hbm_total, sink, K2, rows, K2, tile_bytes, span, 5, &cursor));
+    // packed [tile][step][128 rows][128 B]: the same bytes, contiguous per workgroup (ld = 128 B: row r of a step at + 128 r,
+    // the next step 16 KB further: modelled as rows = 128 * steps of 128 B each, one step)
+    line("packed [tile][k-step][128 rows][128 B]: each workgroup's 1.31 MB contiguous",
+         run_tile<128>(G, (const unsigned char*)hbm, hbm_total, sink, 128, (int)(rows * (K2 / 128)), 128, tile_bytes, span, 5, &cursor));
   }
   return 0;
 }
