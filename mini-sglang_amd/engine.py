@@ -95,6 +95,7 @@ class EngineConfig:
     tp_cpu_group: Any = None  # torch.distributed CPU group of the TP ranks (pool sizing agreement)
     gemm_tune: str = "heuristic"  # "off" | "heuristic" | "full": library solution search per graph batch size
     refine_in_graph: bool = True  # re-rank the search's finalists at the largest graph batch inside the captured step
+    prefill_tokens: Optional[int] = None  # the scheduler's max_extend_tokens: library solution search at that chunk size too
     seed: int = 42
 
     @property
@@ -258,7 +259,8 @@ class Engine:
         bs_list = determine_graph_bs(cfg.cuda_graph_bs, cfg.cuda_graph_max_bs, free_before)
         bs_list = [b for b in bs_list if b <= cfg.max_running_req]
         # solution search happens before capture (it synchronises); full search only where it pays
-        self.gemm_report = self.model.tune_gemms(bs_list, cfg.gemm_tune)
+        self.gemm_report = self.model.tune_gemms(bs_list, cfg.gemm_tune,
+                                                 prefill_tokens=[cfg.prefill_tokens] if cfg.prefill_tokens else ())
         self.graph_runner = GraphRunner(self, bs_list)
         self.refine_report: List[dict] = []
         if cfg.refine_in_graph and cfg.gemm_tune != "off" and bs_list and cfg.tp_size == 1 and \

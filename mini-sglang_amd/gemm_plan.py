@@ -21,6 +21,30 @@ from . import ops
 Group = Tuple
 
 
+def tune_prefill_gemms(groups: Sequence[Group], prefill_tokens: Sequence[int], dtype: torch.dtype, device: torch.device,
+                       log: Optional[Callable[[str], None]] = None) -> List[dict]:
+    """Library solution search at PREFILL chunk sizes.  A chunked-prefill forward under load carries exactly
+    `max_extend_tokens` tokens (P/scheduler/prefill.py:65-90 fills the budget), the reference's default being 8192
+    (P/scheduler/config.py:16): at that M the library's heuristic pick is 1.4x off its best solution for o_proj and down_proj
+    (tools/prefill_gemm_probe.py; at 16384 the heuristic already is the best of 230).  Library only -- the hand-written
+    kernels stop at M = 256 -- the 16 solutions the library ranks first, no split-K; the plan is keyed by the exact M, every
+    other chunk size keeps the heuristic.  The LM head is skipped (a prefill forward projects one row per finished request)."""
+    report: List[dict] = []
+    for M in sorted(set(int(m) for m in prefill_tokens if int(m) > ops.M256_MAX_M)):
+        for grp in groups:
+            name, ws, k = grp[0], list(grp[1]), grp[2]
+            if name == "lm_head":
+                continue
+            x = torch.randn((M, k), device=device, dtype=torch.float32).to(dtype)
+            r = ops.gemm_tune(x, ws, max_candidates=-16, iters=3, split_k=False)
+            r.update(name=name, prefill=True)
+            report.append(r)
+            if log is not None:
+                log(f"[gemm_tune] prefill M={M} {name}: {r['default_us']:.1f} -> {r['best_us']:.1f} us ({r['tried']} candidates)")
+            del x
+    return report
+
+
 def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], mode: str, dtype: torch.dtype,
                           device: torch.device, log: Optional[Callable[[str], None]] = None) -> List[dict]:
     """mode: "off", "heuristic" (library's top 16 + hand-written kernels), "full" (every library solution at the

@@ -261,10 +261,13 @@ class DenseDecoder:
                 ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size, {"silu_interleaved": self.gate_up_ilv}),
                 ("down", [l.down for l in pick], self.inter), ("lm_head", [self.lm_head], self.cfg.hidden_size)]
 
-    def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None) -> List[dict]:
-        from .gemm_plan import tune_projection_gemms
+    def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None, prefill_tokens=()) -> List[dict]:
+        from .gemm_plan import tune_prefill_gemms, tune_projection_gemms
 
-        return tune_projection_gemms(self.projection_groups(), batch_sizes, mode, self.dtype, self.device, log=log)
+        report = tune_projection_gemms(self.projection_groups(), batch_sizes, mode, self.dtype, self.device, log=log)
+        if mode != "off" and prefill_tokens:  # after the decode search: "off" resets every plan
+            report += tune_prefill_gemms(self.projection_groups(), prefill_tokens, self.dtype, self.device, log=log)
+        return report
 
     # ------------------------------------------------------------------ row-parallel projection + all-reduce
     def row_parallel(self, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

@@ -500,3 +500,26 @@ def test_split_k_reduce_folded_into_qk_norm_rope_store(ops, dev, dtype, M, hq, h
     finally:
         ops._M256_PLAN.clear()
         ops._PENDING_SLABS.clear()
+
+
+def test_prefill_chunk_gemm_search_keeps_results_and_records_a_plan(dev):
+    """gemm_plan.tune_prefill_gemms (round 4): the library solution search at a prefill chunk size M (the scheduler's
+    max_extend_tokens) -- the tuned solution is still x @ w^T, the LM head is skipped, nothing at M <= 256 is touched."""
+    import torch.nn.functional as F
+
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.gemm_plan import tune_prefill_gemms
+
+    g = torch.Generator(device=dev).manual_seed(5)
+    M, N, K = 1024, 1536, 512
+    ws = [(torch.randn((N, K), generator=g, device=dev) * 0.05).to(torch.bfloat16) for _ in range(2)]
+    head = [(torch.randn((2048, K), generator=g, device=dev) * 0.05).to(torch.bfloat16)]
+    x = torch.randn((M, K), generator=g, device=dev).to(torch.bfloat16)
+    try:
+        rep = tune_prefill_gemms([("o", ws, K), ("lm_head", head, K)], [M, 128], torch.bfloat16, dev)
+        assert [r["name"] for r in rep] == ["o"] and rep[0]["M"] == M and rep[0]["tried"] >= 1 and rep[0]["best_us"] <= rep[0]["default_us"] * 1.001
+        ref = F.linear(x.float(), ws[1].float())
+        got = ops.linear(x, ws[1]).float()
+        assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    finally:
+        ops.reset_gemm_plans()
