@@ -401,7 +401,7 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
         "ttft_p50_ms": ttft_p50,
         "small_batch_ms_per_step": small,
         "roofline": {
-            "bound": "hbm", "kernel": "attn_decode_mfma_kernel incl. the split-KV merge (in-kernel at this batch), one layer", "achieved": achieved,
+            "bound": "hbm", "kernel": "attn_decode_mfma_kernel (+merge), one layer", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_source": traffic_src, "traffic_over_algorithmic": traffic_ratio, "us_per_launch": attn_us,
             "algorithmic_bytes": attn_bytes, "launch_shape": shape,

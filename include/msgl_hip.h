@@ -177,13 +177,13 @@ int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, i
  * min_chunk: smallest slot in tokens (power of two >= 16).  The plan buffer
  * must be 16-byte aligned; plan[0] = pieces, [1] = tokens per slot, [3] = slots.
  * ---------------------------------------------------------------------- */
-/* Combining the split-KV partial sums.  Batches below 192 requests: a merge kernel follows the partial kernel.  Full
- * batches (>= 192 requests; round 4, forced by msgl_attn_decode_select(72), forbidden by 71): the piece of a request that
- * arrives LAST (per-(request, kv head) arrival counters at the end of the plan buffer, zeroed by msgl_attn_decode_plan and
- * left at zero by every launch) reads the others' partial sums -- published write-through -- and writes the output itself,
- * in piece order with the merge kernel's arithmetic: same bits, one launch per layer less (worth 45 us per 256-sequence
- * step inside the captured graph, profiles/r04*_step_ab*.json); msgl_attn_decode then WRITES those counters inside `plan`.
- */
+/* Combining the split-KV partial sums: a merge kernel follows the partial kernel.  Alternative kept for measurement
+ * (msgl_attn_decode_select(72)): the piece of a request that arrives LAST (per-(request, kv head) arrival counters at the end
+ * of the plan buffer, zeroed by msgl_attn_decode_plan and left at zero by every launch) reads the others' partial sums --
+ * published write-through -- and writes the output itself, in piece order with the merge kernel's arithmetic: same bits,
+ * one launch per layer less; inside the captured Qwen3-14B step worth 0 .. 45 us per step, on the TP-shard shapes and small
+ * batches 3 .. 8 us per layer SLOWER (profiles/r04_decode_ab.txt), hence opt-in; msgl_attn_decode then WRITES those
+ * counters inside `plan`. */
 /* number of int32 words the plan buffer needs */
 int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);
 /* bytes of fp32 workspace for split-KV partials */
@@ -201,8 +201,7 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
  * launch must be made under the same choice): 0 = default (matrix-core kernel for slot_run >= 16, streaming kernel
  * otherwise), 1 = streaming kernel only; for timing and diagnosis also 10 w + s = matrix-core kernel held to w waves
  * per SIMD with an s-stage request ring (22, 23, 24, 32), 72 = variant 22 with the in-kernel combine instead of
- * the merge kernel (round 4: what the default does for batches of >= 192 requests), 71 = the default variant with the
- * merge kernel forced, 92 = variant 22 with the products left out (what the request pattern alone costs), 93 =
+ * the merge kernel, 71 = the default variant by number (72's A/B partner), 92 = variant 22 with the products left out (what the request pattern alone costs), 93 =
  * variant 22 leaving clock stamps (msgl_attn_decode_trace).  Also settable by
  * MSGL_DECODE_IMPL before the first call.  Both kernels meet the same tolerance against the oracle. */
 int msgl_attn_decode_select(int impl);

@@ -1066,14 +1066,14 @@ template <typename T, int G>
 static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
   // same number of waves as the plan was made for (decode_target_slots): any grid >= n_slots * hv is correct
   const int64_t waves = (int64_t)decode_target_slots(G, p.hv, capacity, p.max_bs) * p.hv;
-  // In-kernel combine: the last-arriving piece of a request combines the partial sums inside the kernel instead of the merge
+  // select code 72: the last-arriving piece of a request combines the partial sums inside the kernel instead of the merge
   // launch (needs the arrival counters to cover the kv heads and 32-bit offsets into the partial sums).  Bit-identical
-  // to the merge kernel.  Stand-alone it measures equal at B = 256 and 4-5 us slower at B = 32 (the combiner's three
-  // dependent sc1 round trips sit at the very end of the kernel: profiles/r02d_decode_attention_findings.txt); INSIDE the
-  // captured 256-sequence step it is worth 45 us per step, three rounds of three agreeing (tools/step_ab.py,
-  // profiles/r04_step_ab.json: one launch boundary per layer less).  So: on for full batches (>= 192 requests), select
-  // code 72 forces it, 71 forbids it.
-  const bool combine = (decode_impl() == 72 || (decode_impl() == 0 && batch >= 192)) && p.hv <= kTicketHeads &&
+  // to the merge kernel.  NOT the default: round 4 measured it INSIDE the captured 256-sequence Qwen3-14B step (tools/
+  // step_ab.py) at -45 / -25 / +-0 us per step on three boxes (one launch boundary per layer less), but stand-alone on the
+  // TP-shard shapes it LOSES 3-6 us per layer (14B TP4 49.1 vs 45.8 us, 70B TP8 35.4 vs 29.6, Qwen3-0.6B 174.3 vs 171.8:
+  // the combiner's dependent sc1 round trips at the very end of a short kernel; profiles/r04_decode_ab.txt) and 8 us at
+  // B = 32.  Select code 71 = the default variant by its number (A/B partner of 72).
+  const bool combine = decode_impl() == 72 && p.hv <= kTicketHeads &&
                        (int64_t)capacity * p.hq * 128 * (int64_t)sizeof(float) < (1ll << 31);
 #define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, ...)                                                    \
   attn_decode_mfma_kernel<T, STAGES, WAVES, MINW, __VA_ARGS__>                                        \

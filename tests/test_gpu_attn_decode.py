@@ -335,28 +335,6 @@ def test_decode_in_kernel_combine_equals_the_merge_kernel(ops, dev, hq, hkv, len
         ops.attn_decode_select(0)
 
 
-def test_decode_default_at_a_full_batch_is_the_in_kernel_combine_and_equals_the_merge_kernel(ops, dev):
-    """Round 4: with >= 192 requests the default (select 0) folds the split-KV merge into the attention kernel (inside the
-    captured 256-sequence step it saves a launch boundary per layer); select 71 keeps the merge kernel.  Same bits; a
-    smaller batch keeps the merge kernel by default."""
-    g = torch.Generator().manual_seed(71)
-    hq, hkv = 40, 8
-    for B in (256, 64):
-        lens = [int(x) for x in torch.randint(100, 1900, (B,), generator=g)]
-        case = make_case(g, B, hq, hkv, lens, 256)
-        try:
-            ops.attn_decode_select(71)
-            want, plan = run_decode(ops, dev, case, slot_run=256, min_chunk=64)
-            assert int(plan[0]) > B, "the scenario must split requests"
-            torch.testing.assert_close(want.double(), oracle(case), **TOL)
-            ops.attn_decode_select(0)
-            for _ in range(2):
-                got, _ = run_decode(ops, dev, case, slot_run=256, min_chunk=64)
-                assert torch.equal(got, want), B
-        finally:
-            ops.attn_decode_select(0)
-
-
 def _combine_checks(ops, dev, case, lens, hq, hkv, want):
     for _ in range(3):
         got, _ = run_decode(ops, dev, case, slot_run=256, min_chunk=64)

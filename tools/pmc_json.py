@@ -33,10 +33,12 @@ def avg_us(path):
     return out
 
 
-def pick(d, key):
+def pick(d, key, default=None):
     for k, v in d.items():
         if key in k:
             return v
+    if default is not None:
+        return default
     raise KeyError(key)
 
 
@@ -62,14 +64,15 @@ def main():
     write_ratio = cw[1] * 1024 / (3 * GIB)
     corr = 1.0 / fetch_ratio
     kname, fa = pick_attn(f)
-    fa, fm = fa[2], pick(f, "attn_decode_merge")[2]
-    wa, wm = pick_attn(w)[1][2], pick(w, "attn_decode_merge")[2]
+    # round 4: at full batches the split-KV merge runs INSIDE the attention kernel (no merge dispatch: zeros)
+    fa, fm = fa[2], pick(f, "attn_decode_merge", (0, 0, 0.0))[2]
+    wa, wm = pick_attn(w)[1][2], pick(w, "attn_decode_merge", (0, 0, 0.0))[2]
     hbm = ((fa + fm) * corr + (wa + wm) / write_ratio) * 1024
-    ta, tm = pick_attn(t)[1], pick(t, "attn_decode_merge")
+    ta, tm = pick_attn(t)[1], pick(t, "attn_decode_merge", 0.0)
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and --kernel-trace --stats "
                   "-- python tools/profile_attn.py, MI355X" + (", " + note if note else ""),
-        "workload": f"{kname.split('(')[0][:60]} + merge, Qwen3-14B TP1 shape, B=256, bench contexts + 46 "
+        "workload": f"{kname.split('(')[0][:60]} + merge (in-kernel when no merge dispatch is listed), Qwen3-14B TP1 shape, B=256, bench contexts + 46 "
                     "(= bench.py's roofline launch at default steps), page_size 256",
         "launch_shape": "qwen3-14b tp1 B256 page256 bench_contexts",
         "algorithmic_bytes_per_launch": algo,

@@ -62,8 +62,8 @@ def main():
         row["dma == tr (bitwise)"] = bool(torch.equal(outs[2], outs[4]))
         runs = [("tr: " + label, c, (16 + bits) if bits else 2) for bits, label in VARIANTS.items()]
         runs += [("dma: " + label, c, (64 + bits) if bits else 4) for bits, label in DMA_VARIANTS.items()]
-        if args.only:
-            runs = [r for r in runs if any(r[0].startswith(o) for o in args.only)]
+        if args.only:  # exact labels ("dma: full") or prefixes ending in a space ("dma: ")
+            runs = [r for r in runs if any(r[0] == o or (o.endswith(" ") and r[0].startswith(o)) for o in args.only)]
         best = {}
         for _ in range(args.rounds):  # variants interleaved, best of the rounds: the first launches after a change of kernel run slower
             for label, cc, impl in runs:

@@ -7,8 +7,8 @@ re-captured and replayed, rounds interleaved, median of individually timed repla
 
 knobs:
     decode72      paged decode attention with the split-KV merge folded into the last-arriving piece (msgl_attn_decode_select 72)
-                  instead of the separate merge kernel (round 4: the default at >= 192 requests)
-    decode71      the separate merge kernel forced (what round 3 ran)
+                  instead of the separate merge kernel
+    decode71      the default variant by its number (72's A/B partner)
     decode1       the streaming (VALU) decode attention kernel
     no_slab_norm  o_proj / down_proj slabs reduced by their own launch instead of by the following norm
     lib_o / lib_qkv / lib_down / lib_gate_up     the library's best solution for that projection instead of the planned kernel
