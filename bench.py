@@ -57,8 +57,8 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
     table) + embedding, final norm and LM head, x num_layers.  A reported baseline, not a target."""
     from oracle import ref_model
 
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MSGL_CPU_BASELINE_THREADS", "64")))
-    torch.set_num_threads(cores)
+    avail = len(os.sched_getaffinity(0))
+    forced = os.environ.get("MSGL_CPU_BASELINE_THREADS")
     B, L = len(contexts), 1
     lens = [int(n) for n in contexts]
     D = cfg.head_dim
@@ -81,7 +81,18 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
         ref_model.forward(cfg, weights, ids, pos, loc, kp, vp, table, list(range(B)), cur, [1] * B, False)
         return time.perf_counter() - t0
 
+    # thread count: torch-eager on a many-core host is not monotone in threads (the per-request attention loop and the
+    # M = 256 GEMMs want different counts; 64 threads measured 3.5x SLOWER per layer than 8 on one box): one layer at each
+    # of a few counts, the fastest is the baseline's (and is what `cores` reports)
+    counts = [int(forced)] if forced else sorted({c for c in (8, 16, 32, 64) if c <= avail} or {avail})
+    torch.set_num_threads(counts[0])
     run(no_head, lens)  # warm-up (thread pool, allocator)
+    probe = {}
+    for c in counts:
+        torch.set_num_threads(c)
+        probe[c] = run(no_head, lens)
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
     t_layer, t_full = [], []
     for i in range(rounds):
         cur = [n + i + 1 for n in lens]
@@ -95,7 +106,8 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
                 sample=f"torch-eager fp32 oracle, {cfg.name} dims, the GPU step's own batch: {B} requests, contexts mean "
                        f"{sum(lens) / B:.0f} through a page table; {L} of {cfg.num_layers} decoder layers timed "
                        f"({lay * 1e3:.0f} ms, median of {rounds}) x {cfg.num_layers // L} + embedding / final norm / LM head "
-                       f"({head * 1e3:.0f} ms): {est_step * 1e3:.0f} ms/step")
+                       f"({head * 1e3:.0f} ms): {est_step * 1e3:.0f} ms/step; threads tried (s per layer): "
+                       + ", ".join(f"{c}: {t:.2f}" for c, t in probe.items()))
 
 
 def pmc_traffic(attn_bytes: int, shape: str):
