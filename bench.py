@@ -534,14 +534,18 @@ def main() -> None:
     mcfg = PRESETS[args.model]
     contexts = bench_contexts(args.batch)
     ms_per_step = result["ms_per_step"]
-    if world == 4 and args.model == "qwen3-14b" and not args.no_second_config:
-        # the metric's second configuration (BASELINE.json: "Qwen3-32B TP=4"): the same request set on Qwen3-32B
+    # the metric's second configuration (BASELINE.json: "Qwen3-32B TP=4"): at --gpus 4 the same request set on Qwen3-32B.
+    # $MSGL_BENCH_SECOND_MODEL runs a second workload at any N (how the two-workloads-in-one-process path -- communicators
+    # torn down and rebuilt, a second engine in the freed memory -- is exercised on a 1-GPU box with a small model)
+    second = os.environ.get("MSGL_BENCH_SECOND_MODEL") or ("qwen3-32b" if world == 4 and args.model == "qwen3-14b" else None)
+    if second and not args.no_second_config:
+        key = "qwen3_32b_tp4" if (second == "qwen3-32b" and world == 4) else f"second_config_{second}_tp{world}"
         try:
-            r32 = run_workload(args, "qwen3-32b", rank, local_rank, world, device, share_gpu, primary=False)
-            result["qwen3_32b_tp4"] = {k: r32[k] for k in ("value", "unit", "ms_per_step", "ttft_p50_ms", "config", "roofline",
-                                                            "step_roofline", "collectives", "gemm_plans_at_full_batch") if k in r32}
+            r2 = run_workload(args, second, rank, local_rank, world, device, share_gpu, primary=False)
+            result[key] = {k: r2[k] for k in ("value", "unit", "ms_per_step", "ttft_p50_ms", "config", "roofline",
+                                              "step_roofline", "collectives", "gemm_plans_at_full_batch") if k in r2}
         except Exception as e:
-            result["qwen3_32b_tp4"] = {"error": f"{type(e).__name__}: {e}"}
+            result[key] = {"error": f"{type(e).__name__}: {e}"}
     # what the REFERENCE's own LLM / Scheduler / GraphRunner measure on this path through the plugin: recorded by
     # tests/test_gpu_reference_driven.py (it may import oracle/_ref, this file may not) and committed under profiles/
     ref_runs = sorted((ROOT / "profiles").glob("r*_refdrive_14b.json"))

@@ -182,7 +182,7 @@ int msgl_gelu_and_mul(void* out, const void* x, int64_t num_tokens, int64_t d, i
  * of the plan buffer, zeroed by msgl_attn_decode_plan and left at zero by every launch) reads the others' partial sums --
  * published write-through -- and writes the output itself, in piece order with the merge kernel's arithmetic: same bits,
  * one launch per layer less; inside the captured Qwen3-14B step worth 0 .. 45 us per step, on the TP-shard shapes and small
- * batches 3 .. 8 us per layer SLOWER (profiles/r04_decode_ab.txt), hence opt-in; msgl_attn_decode then WRITES those
+ * batches 3 .. 8 us per layer SLOWER (profiles/r04_decode_ab_with_combine_as_impl0.txt, r04_decode_ab_final.txt), hence opt-in; msgl_attn_decode then WRITES those
  * counters inside `plan`. */
 /* number of int32 words the plan buffer needs */
 int64_t msgl_attn_decode_plan_words(int max_bs, int capacity);

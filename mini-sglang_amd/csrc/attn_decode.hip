@@ -1071,7 +1071,7 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
   // to the merge kernel.  NOT the default: round 4 measured it INSIDE the captured 256-sequence Qwen3-14B step (tools/
   // step_ab.py) at -45 / -25 / +-0 us per step on three boxes (one launch boundary per layer less), but stand-alone on the
   // TP-shard shapes it LOSES 3-6 us per layer (14B TP4 49.1 vs 45.8 us, 70B TP8 35.4 vs 29.6, Qwen3-0.6B 174.3 vs 171.8:
-  // the combiner's dependent sc1 round trips at the very end of a short kernel; profiles/r04_decode_ab.txt) and 8 us at
+  // the combiner's dependent sc1 round trips at the very end of a short kernel; profiles/r04_decode_ab_with_combine_as_impl0.txt, r04_decode_ab_final.txt) and 8 us at
   // B = 32.  Select code 71 = the default variant by its number (A/B partner of 72).
   const bool combine = decode_impl() == 72 && p.hv <= kTicketHeads &&
                        (int64_t)capacity * p.hq * 128 * (int64_t)sizeof(float) < (1ll << 31);

@@ -86,18 +86,20 @@ timeout 100 python tools/skinny_silu_bench.py --out gpurun_out/${TAG}_skinny_sil
 # measurement; --gpus 4 also runs the Qwen3-32B TP4 entry); what one CU's memory pipe delivers by source (tools/cu_pipe_probe.hip);
 # kernel choices A/B'd inside the captured step; BASELINE config 4 as a scheduler-level trace replay (Qwen3-32B, TP1 here)
 cd $R
-for N in 2 4; do
-  ( time MSGL_BENCH_SHARE_GPU=1 MSGL_GEMM_TUNE=off timeout 500 python bench.py --gpus $N --steps 3 --warmup 1 ) > gpurun_out/${TAG}_bench_tp${N}_ranks_on_one_gpu_code_path_check.json 2> gpurun_out/${TAG}_bench_tp${N}_share.err
-  python - <<PY
+# (four 14B ranks time-slicing ONE GPU did not finish in 15 minutes -- three spinning peers starve the fourth -- so the N = 4
+# code path (second workload in the same processes: communicators torn down and rebuilt) runs at N = 2 on a small model)
+( time MSGL_BENCH_SHARE_GPU=1 MSGL_GEMM_TUNE=off timeout 500 python bench.py --gpus 2 --steps 3 --warmup 1 ) > gpurun_out/${TAG}_bench_tp2_ranks_on_one_gpu_code_path_check.json 2> gpurun_out/${TAG}_bench_tp2_share.err
+( time MSGL_BENCH_SHARE_GPU=1 MSGL_GEMM_TUNE=off MSGL_BENCH_SECOND_MODEL=qwen3-0.6b timeout 400 python bench.py --gpus 2 --model qwen3-0.6b --steps 3 --warmup 1 ) > gpurun_out/${TAG}_bench_tp2_two_workloads_code_path_check.json 2> gpurun_out/${TAG}_bench_tp2_two_share.err
+python - <<PY
 import json
-try:
-    d = json.loads(open("gpurun_out/${TAG}_bench_tp${N}_ranks_on_one_gpu_code_path_check.json").read().strip().splitlines()[-1])
-    print("self-launched --gpus ${N} on one GPU:", d["launch"], "| ms/step", round(d["ms_per_step"], 1), "|", d["collectives"]["paths"],
-          "| 32B entry:", {k: (round(v, 1) if isinstance(v, float) else v) for k, v in d.get("qwen3_32b_tp4", {}).items() if k in ("ms_per_step", "error")})
-except Exception as e:
-    print("self-launch --gpus ${N}: unreadable:", e)
+for f in ("gpurun_out/${TAG}_bench_tp2_ranks_on_one_gpu_code_path_check.json", "gpurun_out/${TAG}_bench_tp2_two_workloads_code_path_check.json"):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print("self-launched --gpus 2 on one GPU:", d["launch"], "| ms/step", round(d["ms_per_step"], 1), "|", d["collectives"]["paths"],
+              "| second workload:", {k: ({kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("ms_per_step", "error")}) for k, v in d.items() if k.startswith("second_config") or k == "qwen3_32b_tp4"})
+    except Exception as e:
+        print("self-launch check unreadable:", f, e)
 PY
-done
 timeout 120 tools/build/cu_pipe_probe > gpurun_out/${TAG}_cu_pipe_probe.txt 2>&1; tail -13 gpurun_out/${TAG}_cu_pipe_probe.txt | cut -c1-200
 timeout 400 python tools/step_ab.py --rounds 3 --knobs decode72 decode71 lib_o lib_gate_up no_slab_norm --out gpurun_out/${TAG}_step_ab.json 2>&1 | tail -2 | cut -c1-600
 timeout 900 python tools/trace_replay.py --model qwen3-32b --requests 300 --rate 6.0 --out gpurun_out/${TAG}_trace_replay_qwen3-32b_tp1.json 2>&1 | tail -2 | cut -c1-700
