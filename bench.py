@@ -173,18 +173,25 @@ def self_launch(gpus: int) -> int:
     """`python3 bench.py --gpus N` with no launcher around it: start the N ranks through torch.distributed.run (one
     process per GPU, loopback rendezvous on a free port) and hand back its exit code; rank 0's JSON line goes to this
     process's stdout."""
-    import socket
     import subprocess
+
+    cmd, env = self_launch_command(gpus, sys.argv[1:])
+    return subprocess.call(cmd, env=env)
+
+
+def self_launch_command(gpus: int, argv):
+    """(command, environment) of the self-launch: the driver's own contract line for N > 1 with this file's arguments."""
+    import socket
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                MSGL_BENCH_SELF_LAUNCHED="1")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    return cmd, env
 
 
 def check_collectives(comm, rank: int, world: int, device) -> dict:

@@ -80,6 +80,18 @@ class RcclCommunicator:
             self._handle = ctypes.c_void_p()
 
 
+def describe_p2p_error(e: int, rank: int, world_size: int) -> str:
+    """The sticky error word of a peer-to-peer communicator in words (layout: csrc/comm_p2p.hip, `Error word`)."""
+    phase, kind, block, peer, told = (e & 15) - 1, (e >> 4) & 15, (e >> 8) & 255, (e >> 16) & 15, bool(e & (1 << 20))
+    what = {1: "one-shot all-reduce", 2: "two-shot all-reduce", 3: "fused all-reduce + add + RMSNorm", 4: "all-gather"}.get(kind, "collective")
+    if told:
+        return (f"peer-to-peer collective: rank {peer} gave up waiting for a peer in a {what} (barrier phase {phase}, block "
+                f"{block}) and told rank {rank} of {world_size}; outputs of every later collective are NaN-poisoned")
+    return (f"peer-to-peer collective: rank {rank} of {world_size} gave up waiting for a peer (rank {peer}) in a {what} "
+            f"at barrier phase {phase}, block {block} (spin limit reached); outputs of that and every later collective are "
+            "NaN-poisoned")
+
+
 class P2PCommunicator:
     """Peer-to-peer collectives over mapped buffers (csrc/comm_p2p.hip): the symmetric-buffer path of the reference's
     NCCLWrapper (C/src/pynccl.cu:81-90, 105-123) for messages <= max_bytes.  Same surface as PyNCCLCommunicator.
@@ -232,15 +244,7 @@ class P2PCommunicator:
             raise _lib.MsglError(self.describe_error(e))
 
     def describe_error(self, e: int) -> str:
-        """The sticky error word in words (layout: csrc/comm_p2p.hip, `Error word`)."""
-        phase, kind, block, peer, told = (e & 15) - 1, (e >> 4) & 15, (e >> 8) & 255, (e >> 16) & 15, bool(e & (1 << 20))
-        what = {1: "one-shot all-reduce", 2: "two-shot all-reduce", 3: "fused all-reduce + add + RMSNorm", 4: "all-gather"}.get(kind, "collective")
-        if told:
-            return (f"peer-to-peer collective: rank {peer} gave up waiting for a peer in a {what} (barrier phase {phase}, block "
-                    f"{block}) and told rank {self.rank} of {self.world_size}; outputs of every later collective are NaN-poisoned")
-        return (f"peer-to-peer collective: rank {self.rank} of {self.world_size} gave up waiting for a peer (rank {peer}) in a {what} "
-                f"at barrier phase {phase}, block {block} (spin limit reached); outputs of that and every later collective are "
-                "NaN-poisoned")
+        return describe_p2p_error(e, self.rank, self.world_size)
 
     def get_buffer(self) -> int:
         return int(self._lib.msgl_p2p_get_buffer(self._handle) or 0)

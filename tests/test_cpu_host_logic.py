@@ -142,3 +142,42 @@ def test_page_allocator_reproduces_the_reference_cache_manager_trace(golden_dir)
     assert a.free_slots.tolist() == [8, 10, 12, 14, 0, 2, 4]
     with pytest.raises(RuntimeError):
         a.allocate([types.SimpleNamespace(table_idx=0, cached_len=0, device_len=100)])
+
+
+def test_bench_self_launch_command_is_the_drivers_contract_line():
+    """`python3 bench.py --gpus N` outside a launcher re-executes itself through torch.distributed.run: one process per GPU,
+    loopback rendezvous on a free port, this file's own arguments, the dmabuf IPC mode exported."""
+    from pathlib import Path
+
+    import bench
+
+    cmd, env = bench.self_launch_command(4, ["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    i = cmd.index("--master-addr")
+    assert cmd[i + 1] == "127.0.0.1" and cmd[i + 2] == "--master-port" and 1024 <= int(cmd[i + 3]) < 65536
+    j = cmd.index(str(Path(bench.__file__).resolve()))
+    assert cmd[j + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert env["MSGL_BENCH_SELF_LAUNCHED"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_p2p_error_word_decodes_to_a_message_on_both_sides():
+    """csrc/comm_p2p.hip `Error word`: bits 0-3 = 1 + phase, 4-7 = collective kind, 8-15 = block, 16-19 = peer, bit 20 = the
+    copy a failing rank wrote into a peer's header."""
+    from mini_sglang_amd.kernel import describe_p2p_error
+
+    own = (1 + 0) | (2 << 4) | (5 << 8) | (3 << 16)
+    m = describe_p2p_error(own, 0, 4)
+    assert "rank 0 of 4 gave up waiting for a peer (rank 3)" in m and "two-shot all-reduce" in m and "phase 0, block 5" in m
+    told = (1 + 2) | (3 << 4) | (9 << 8) | (1 << 16) | (1 << 20)
+    m = describe_p2p_error(told, 2, 4)
+    assert "rank 1 gave up waiting" in m and "told rank 2 of 4" in m and "fused all-reduce + add + RMSNorm" in m and "phase 2" in m
+
+
+def test_synthetic_qwen_trace_is_deterministic_and_in_range():
+    import refdrive
+
+    a, b = refdrive.synth_qwen_trace(50, 5.0), refdrive.synth_qwen_trace(50, 5.0)
+    assert a == b and len(a) == 50
+    assert all(x["t"] <= y["t"] for x, y in zip(a, a[1:]))
+    assert all(16 <= r["input_length"] <= 6000 and 8 <= r["output_length"] <= 1000 for r in a)
+    assert 5.0 < a[-1]["t"] < 20.0  # ~50 arrivals at 5 / s
