@@ -29,7 +29,9 @@ def run(model, chunk, tuned, dev):
 
     B = 256
     ecfg = EngineConfig(model=PRESETS[model], dtype=torch.bfloat16, max_running_req=B, cuda_graph_bs=[], page_size=256,
-                        max_seq_len_override=4096, memory_ratio=0.9, gemm_tune="heuristic", refine_in_graph=False,
+                        max_seq_len_override=4096, num_page_override=2048,  # a fixed pool that holds the batch: the engines of this
+                        # process follow each other, and the caching allocator keeps the previous pool's memory
+                        gemm_tune="heuristic", refine_in_graph=False,
                         prefill_tokens=chunk if tuned else None)
     eng = Engine(ecfg, dev)
     runner = OfflineRunner(eng, max_extend_tokens=chunk, seed=0)
