@@ -100,6 +100,7 @@ for f in ("gpurun_out/${TAG}_bench_tp2_ranks_on_one_gpu_code_path_check.json", "
     except Exception as e:
         print("self-launch check unreadable:", f, e)
 PY
+[ -x tools/build/cu_pipe_probe ] || { mkdir -p tools/build; hipcc -O3 --offload-arch=gfx950 tools/cu_pipe_probe.hip -o tools/build/cu_pipe_probe; }
 timeout 120 tools/build/cu_pipe_probe > gpurun_out/${TAG}_cu_pipe_probe.txt 2>&1; tail -13 gpurun_out/${TAG}_cu_pipe_probe.txt | cut -c1-200
 timeout 400 python tools/step_ab.py --rounds 3 --knobs decode72 decode71 lib_o lib_gate_up no_slab_norm --out gpurun_out/${TAG}_step_ab.json 2>&1 | tail -2 | cut -c1-600
 timeout 900 python tools/trace_replay.py --model qwen3-32b --requests 300 --rate 6.0 --out gpurun_out/${TAG}_trace_replay_qwen3-32b_tp1.json 2>&1 | tail -2 | cut -c1-700
