@@ -84,6 +84,9 @@ def main():
     for kn in args.knobs:
         if kn.startswith("plan:"):
             knobs[kn] = plan_knob(kn)
+        elif kn.startswith("decode:"):  # any msgl_attn_decode_select code, e.g. decode:73
+            code = int(kn.split(":")[1])
+            knobs[kn] = ((lambda c=code: ops.attn_decode_select(c)), (lambda: ops.attn_decode_select(0)))
     res = {"model": args.model, "batch": B, "plans": {n: ops.current_candidate(k) for n, k in keys.items()}, "base_ms": [], "knobs": {}}
     try:
         for rnd in range(args.rounds):
