@@ -210,8 +210,6 @@ struct DecodeParams {
   float scale_log2;
   unsigned long long* trace;  // diagnosis (msgl_attn_decode_trace): 16 clock stamps per wave, else nullptr
   int* arrivals;              // plan_off_arrivals: per (request, kv head) arrival counters of the matrix-core kernel
-  int prio_mode;              // experiment (select codes 73 / 74): 1 = the younger half of a workgroup's waves at s_setprio 1
-                              // for the whole kernel, 2 = the two halves alternate priority every 8 tiles, 0 = off
 };
 
 struct Tile {
@@ -636,10 +634,6 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
   const int h = gw - slot * p.hv;
   const int n_slots = p.plan[3];
   if (slot >= n_slots) return;
-  // The second-dispatched half of a workgroup's waves (the younger wave of every SIMD) loses the issue arbitration against
-  // its older SIMD partner: on the bench shape waves 0-3 live 250 k clocks, waves 4-7 365 k (profiles/r04_decode_trace.json).
-  const int young = sgpr(wv >= kMfmaWaves / 2 ? 1 : 0);
-  if (p.prio_mode == 1 && young) __builtin_amdgcn_s_setprio(1);
   const int G = sgpr(p.hq / p.hv);
   const int* n_chunks = p.plan + plan_off_n_chunks(p.max_bs);
   const int* slot_first = p.plan + plan_off_slot_first(p.max_bs);
@@ -790,10 +784,6 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
       for (int st = 0; st < kStages; ++st) pre_sl[st] = ncpt[nt0 + min(st, nlt) * 16];
     }
     for (int tix = 0; tix < ntiles; tix += kStages) {
-      if (p.prio_mode == 2) {  // the halves take turns: eight tiles at priority 1, eight at 0
-        if ((((t0 >> 4) + tix) >> 3 & 1) == young) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
 #pragma unroll
       for (int st = 0; st < kStages; ++st) {
         const int cur = tix + st;
@@ -1067,7 +1057,7 @@ static int decode_impl() {
 static int mfma_variant(int G) {
   const int c = decode_impl();
   if (c == 72) return 22;  // variant 22 with the in-kernel combine
-  if (c == 71 || c == 73 || c == 74) return G <= 2 ? 32 : 22;  // the default variant (73 / 74: with a wave-priority experiment)
+  if (c == 71) return G <= 2 ? 32 : 22;  // the default variant, merge kernel forced
   if (c >= 10 && c < 92) return c;
   return G <= 2 && c < 92 ? 32 : 22;
 }
@@ -1155,7 +1145,7 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 71 || impl == 72 || impl == 73 || impl == 74 || impl == 92 || impl == 93 || impl == 94,
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 71 || impl == 72 || impl == 92 || impl == 93 || impl == 94,
                "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
                "w waves per SIMD and s ring stages, 71 / 72 = the default variant with the merge kernel forced / with the "
                "in-kernel combine forced)", impl);
@@ -1247,7 +1237,6 @@ extern "C" int msgl_attn_decode(void* out, const void* q, const void* k_cache, c
   p.slot_run = slot_run;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.trace = g_decode_trace;
-  p.prio_mode = decode_impl() == 74 ? 1 : decode_impl() == 73 ? 2 : 0;
   p.arrivals = const_cast<int*>(plan) + plan_off_arrivals(max_bs, capacity);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
