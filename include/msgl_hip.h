@@ -46,7 +46,7 @@ extern "C" {
 /* dtype codes for logits */
 #define MSGL_F32 2
 
-#define MSGL_ABI_VERSION 4
+#define MSGL_ABI_VERSION 5
 
 /* Last error message of the calling thread ("" if none). */
 const char* msgl_last_error(void);
@@ -290,6 +290,27 @@ int msgl_skinny_gemm_nt(void* out, const void* x, const void* w, int M, int N, i
  * even `slices` (half of the waves stream the gate tile, half the up tile, slices / 2 k-slices each). */
 int msgl_skinny_gemm_silu_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
                              int64_t ldw, int64_t ldo, int dtype, int slices, int row_tiles, void* stream);
+
+/* The same product for the smallest decode batches (1 <= M <= 8) as a pure stream of the weight matrix
+ * (P/layers/linear.py:32,103,124 at batch sizes 1..8): one 8-wave workgroup per CU reads the consecutive rows
+ * [c N / G, (c + 1) N / G) of w as one contiguous window, `depth` (8 or 16) 16-byte loads in flight per lane, x staged
+ * once into LDS, fp32 dot products on the vector units, the eight wave sums of an output added in wave order
+ * (deterministic; the summation order differs from msgl_skinny_gemm_nt's).  K % 512 == 0; x and the per-row partial
+ * sums must fit the CU's LDS (msgl_rowstream_gemm_supported says).  No workspace, capturable.
+ * `mode` folds the neighbouring row kernel of a decoder layer into the staging pass:
+ *   0  out = x . w^T                                                     (x [M, K])
+ *   1  out = (silu(x[:, :K]) * x[:, K:]) . w^T                            (x [M, 2 K]: gate | up halves; the bits of
+ *      msgl_silu_and_mul followed by mode 0 -- P/layers/activation.py:9-12 + down_proj)
+ *   2  as 1 with x in msgl_silu_and_mul_interleaved's layout (blocks of 32: gate, up)
+ *   3  s = x + res_in; res_out = round(s); out = (rmsnorm(s) * gamma) . w^T   (x [M, K] = the previous projection's
+ *      output: msgl_fused_add_rmsnorm -- P/layers/norm.py:33-38 -- followed by mode 0, bit for bit; M <= 4,
+ *      1024 < K <= 8192; res_out must be a different buffer from res_in and x: every workgroup reads them while
+ *      workgroup 0 writes the new residual)
+ * res_in / res_out / gamma / eps / ldr_* are read in mode 3 only (pass NULL / 0 otherwise). */
+int msgl_rowstream_gemm_supported(int M, int N, int K, int mode);
+int msgl_rowstream_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                           int64_t ldo, int dtype, int depth, int mode, const void* res_in, void* res_out,
+                           const void* gamma, float eps, int64_t ldr_in, int64_t ldr_out, void* stream);
 
 /* Same product for mid-size decode batches (1 <= M <= 256; meant for 32 < M): the 8 waves of a workgroup
  * stream different weight rows over the same k range and share the activation tile through LDS.

@@ -24,7 +24,7 @@ BF16, FP16, F32 = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
 PREFILL_QTILE = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _u64, _sz = C.c_uint64, C.c_size_t
@@ -72,6 +72,8 @@ HIP_SIGNATURES = {
     "msgl_sample_from_logits": (_i, [_p, _p, _p, _l, _l, _l, _i, _u64, _u64, _p]),
     "msgl_skinny_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
     "msgl_skinny_gemm_silu_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
+    "msgl_rowstream_gemm_supported": (_i, [_i, _i, _i, _i]),
+    "msgl_rowstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _p, _p, _f, _l, _l, _p]),
     "msgl_wstream_gemm_workspace_bytes": (_l, [_i, _i, _i]),
     "msgl_wstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _l, _p]),
     "msgl_wstream_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),

@@ -36,6 +36,7 @@ HIP_SOURCES = [
     "attn_prefill.hip",
     "sampling.hip",
     "gemm_skinny.hip",
+    "gemm_rowstream.hip",
     "gemm_wstream.hip",
     "gemm_m256.hip",
     "gemm_g3.hip",

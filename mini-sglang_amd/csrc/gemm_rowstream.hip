@@ -1,0 +1,344 @@
+// Row-streaming projection for the smallest decode batches (M <= 8):
+//     out[M, N] = f(x)[M, K] . w[N, K]^T        (torch F.linear layout, bf16 / fp16, fp32 accumulate)
+//
+// At M <= 8 a projection is nothing but the weight matrix read once.  tools/cu_pipe_probe.hip / tools/persist_probe.hip
+// measured what that costs on gfx950: a CU whose waves keep >= 64 KB of 16-byte loads in flight on a CONTIGUOUS private
+// window pulls ~38 B/ns, 256 of them 7.0-7.25 TB/s, and a launch boundary between two such kernels costs 1-2 us.  The
+// matrix-core kernel of gemm_skinny.hip reaches 4.5-5.3 TB/s on the same matrices (profiles/r04_b1_kernel_breakdown.txt):
+// 16-row workgroups that live for one or two load batches, K split over the waves of a workgroup, N / 16 workgroups
+// quantised against 256 CUs (down_proj: 320 tiles, 160 workgroups of two).  This kernel is the probe with a dot product:
+//   * ONE workgroup (8 waves) per CU; CU c owns the consecutive rows [c N / G, (c + 1) N / G) -- balanced to one row
+//     whatever N is -- i.e. one contiguous window of the weight matrix;
+//   * the window is cut into 1-KB units (64 lanes x 16 B of one row); wave v takes units v, v + 8, ... so the eight
+//     waves walk the window together, each with D (8 / 16) units in flight in a register ring: 64 / 128 KB per CU;
+//   * x (all M rows, <= 139 KB) is staged ONCE into LDS behind the first D weight loads; a unit costs M ds_read_b128 and
+//     4 M v_dot2 per lane (VALU: at M <= 4 under a third of what the weight stream leaves room for);
+//   * a wave keeps per-lane partial sums of the row it is in and, when its units move to the next row, reduces them over
+//     its lanes and parks the sum in LDS [row][wave][m]; after the stream the eight wave sums of a row are added in
+//     wave order (deterministic) and rounded once.
+// The staging pass is where the neighbouring row kernels of a decode layer fold in (mode):
+//   1 / 2  x is a gate_up output [M, 2 K] (halves / interleaved in blocks of 32): stages silu(gate) * up -- the bits of
+//          msgl_silu_and_mul[_interleaved] -- and the activation launch disappears;
+//   3      x is the previous projection's output: stages fused_add_rmsnorm(x, residual) (every workgroup computes the
+//          row statistics itself, in the order of rmsnorm_wide_row_kernel: same bits), workgroup 0 writes the new
+//          residual to `res_out` (a different buffer: the other workgroups are still reading `res_in`).
+// M is padded to 1 / 2 / 4 / 8 staged rows (zeros).  K must be a multiple of 512.
+#include <type_traits>
+
+#include "common.h"
+
+namespace msgl {
+
+typedef uint32_t RW4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRsWaves = 8;
+constexpr int kRsThreads = 64 * kRsWaves;
+constexpr int kRsUnit = 512;              // elements of one unit: 64 lanes x 8
+constexpr int kRsLdsBudget = 159 * 1024;  // dynamic LDS a workgroup may ask for (160 KB per CU, 512 B static)
+
+enum { kRsPlain = 0, kRsSiluHalves = 1, kRsSiluIlv = 2, kRsAddNorm = 3 };
+
+struct RowStreamParams {
+  uint16_t* out;
+  const uint16_t* x;
+  const uint16_t* w;
+  int M, N, K;
+  int64_t ldx, ldw, ldo;
+  // mode 3
+  const uint16_t* res_in;
+  uint16_t* res_out;
+  const uint16_t* gamma;
+  float eps;
+  int64_t ldr_in, ldr_out;
+};
+
+__host__ __device__ constexpr int rs_padded_rows(int M) { return M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8; }
+
+static inline int64_t rs_lds_bytes(int M, int N, int K, int G) {
+  const int mm = rs_padded_rows(M);
+  const int64_t rows = ((int64_t)N + G - 1) / G;
+  return (int64_t)mm * K * 2 + rows * kRsWaves * mm * 4;
+}
+
+template <typename T, int MM, int D, int MODE>
+__global__ __launch_bounds__(kRsThreads, 2) void rowstream_gemm_kernel(const RowStreamParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+  __shared__ float red[8][16];  // mode 3: [staged row][64-piece group]
+  const int K = p.K;
+  uint16_t* xs = reinterpret_cast<uint16_t*>(rs_smem);                  // [MM][K]
+  float* part = reinterpret_cast<float*>(rs_smem + (size_t)MM * K * 2);  // [rows][8 waves][MM]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = sgpr(tid >> 6);
+  const int G = gridDim.x, c = blockIdx.x;
+  const int r0 = (int)((int64_t)c * p.N / G), r1 = (int)((int64_t)(c + 1) * p.N / G);
+  const int rows = r1 - r0;
+  const int UR = K >> 9;        // units per row
+  const int total = rows * UR;  // units of this workgroup
+  const uint16_t* wrow0 = p.w + (int64_t)r0 * p.ldw;
+
+  // unit u of the workgroup = (row u / UR, k-chunk u % UR); a wave steps by 8 units.  Past the end a wave keeps asking
+  // for the matrix's first KB (cache hits): the loads of the ring stay unconditional, the wait counts exact.
+  auto unit_ptr = [&](int u, int row, int kc) {
+    const uint16_t* q = u < total ? wrow0 + (int64_t)row * p.ldw + kc * kRsUnit : p.w;
+    return reinterpret_cast<const RW4*>(q + lane * 8);
+  };
+  auto advance = [&](int& u, int& row, int& kc) {
+    u += kRsWaves;
+    kc += kRsWaves;
+    while (kc >= UR) {
+      kc -= UR;
+      ++row;
+    }
+  };
+
+  RW4 ring[D];
+  int lu = wv, lrow = wv / UR, lkc = wv - lrow * UR;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    ring[j] = __builtin_nontemporal_load(unit_ptr(lu, lrow, lkc));
+    advance(lu, lrow, lkc);
+  }
+
+  for (int i = tid; i < rows * kRsWaves * MM; i += kRsThreads) part[i] = 0.f;
+
+  // ---- stage f(x) into LDS ----
+  const int pieces = K >> 3;
+  if constexpr (MODE == kRsAddNorm) {
+    // rmsnorm_wide_row_kernel (norm_rope_act.hip) runs one row on `pieces` threads, thread q = piece q: per-piece fma
+    // chain, wave_sum over the 64 pieces of a wave, waves added in index order.  Here thread t holds pieces t and
+    // t + 512 -- lane and 64-piece group are the same as there -- and the wave sums land in red[m][group].
+    const int nw = (pieces + 63) >> 6;
+    float v[MM][2][8];
+    U4 gq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + kRsThreads * i;
+      gq[i] = q < pieces ? ldg16(p.gamma + q * 8) : U4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = tid + kRsThreads * i;
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[m][i][e] = 0.f;
+        if (q < pieces && m < p.M) {
+          float rr[8];
+          unpack8<T>(ldg16(p.x + (int64_t)m * p.ldx + q * 8), v[m][i]);
+          unpack8<T>(ldg16(p.res_in + (int64_t)m * p.ldr_in + q * 8), rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[m][i][e] += rr[e];
+          if (c == 0) stg16(p.res_out + (int64_t)m * p.ldr_out + q * 8, pack8<T>(v[m][i]));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss = fmaf(v[m][i][e], v[m][i][e], ss);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[m][wv + kRsWaves * i] = ss;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      float tot = 0.f;
+      for (int i = 0; i < nw; ++i) tot += red[m][i];
+      const float inv = rsqrtf(tot / (float)K + p.eps);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = tid + kRsThreads * i;
+        if (q < pieces) {
+          float g[8], y[8];
+          unpack8<T>(gq[i], g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(__fmul_rn(v[m][i][e], inv), g[e]);
+          *reinterpret_cast<U4*>(xs + (size_t)m * K + q * 8) = m < p.M ? pack8<T>(y) : U4{0, 0, 0, 0};
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const uint16_t* xr = p.x + (int64_t)m * p.ldx;
+      for (int q = tid; q < pieces; q += kRsThreads) {
+        U4 o = U4{0, 0, 0, 0};
+        if (m < p.M) {
+          if constexpr (MODE == kRsPlain) {
+            o = ldg16(xr + q * 8);
+          } else {
+            const int k = q * 8;
+            const int gcol = MODE == kRsSiluIlv ? (k >> 5) * 64 + (k & 31) : k;
+            const int ucol = MODE == kRsSiluIlv ? gcol + 32 : K + k;
+            float g[8], u[8], y[8];
+            unpack8<T>(ldg16(xr + gcol), g);
+            unpack8<T>(ldg16(xr + ucol), u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = silu_mul_f32(g[e], u[e]);
+            o = pack8<T>(y);
+          }
+        }
+        *reinterpret_cast<U4*>(xs + (size_t)m * K + q * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- the stream ----
+  float acc0[MM], acc1[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc0[m] = acc1[m] = 0.f;
+  auto flush = [&](int row) {
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+      const float s = wave_sum(acc0[m] + acc1[m]);
+      if (lane == 0) part[(row * kRsWaves + wv) * MM + m] = s;
+      acc0[m] = acc1[m] = 0.f;
+    }
+  };
+  int cu = wv, crow = wv / UR, ckc = wv - crow * UR;
+  int cur_row = crow;
+  while (cu < total) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      if (cu < total) {
+        if (crow != cur_row) {
+          flush(cur_row);
+          cur_row = crow;
+        }
+        const RW4 wq = ring[j];
+        const uint16_t* xk = xs + ckc * kRsUnit + lane * 8;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+          const RW4 xv = *reinterpret_cast<const RW4*>(xk + (size_t)m * K);
+          acc0[m] = Elem<T>::dot2(wq.x, xv.x, acc0[m]);
+          acc1[m] = Elem<T>::dot2(wq.y, xv.y, acc1[m]);
+          acc0[m] = Elem<T>::dot2(wq.z, xv.z, acc0[m]);
+          acc1[m] = Elem<T>::dot2(wq.w, xv.w, acc1[m]);
+        }
+      }
+      ring[j] = __builtin_nontemporal_load(unit_ptr(lu, lrow, lkc));
+      advance(lu, lrow, lkc);
+      advance(cu, crow, ckc);
+    }
+  }
+  if (wv < total) flush(cur_row);
+  __syncthreads();
+
+  // ---- the eight wave sums of every (row, m), in wave order; consecutive threads write consecutive columns ----
+  for (int i = tid; i < rows * MM; i += kRsThreads) {
+    const int m = i / rows, r = i - m * rows;
+    if (m < p.M) {
+      float s = 0.f;
+#pragma unroll
+      for (int v2 = 0; v2 < kRsWaves; ++v2) s += part[(r * kRsWaves + v2) * MM + m];
+      p.out[(int64_t)m * p.ldo + r0 + r] = (uint16_t)Elem<T>::bits(s);
+    }
+  }
+}
+
+template <typename T, int MM, int D, int MODE>
+static int launch_rowstream_t(const RowStreamParams& p, int G, size_t lds, hipStream_t s) {
+  static bool attr_done = false;  // per instantiation: more than 64 KB of dynamic LDS has to be requested
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rowstream_gemm_kernel<T, MM, D, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBudget) != hipSuccess) {
+      set_error("rowstream_gemm_nt: cannot reserve %d bytes of LDS: %s", kRsLdsBudget, hipGetErrorString(hipGetLastError()));
+      return MSGL_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  rowstream_gemm_kernel<T, MM, D, MODE><<<dim3((unsigned)G), dim3(kRsThreads), lds, s>>>(p);
+  return MSGL_OK;
+}
+
+template <typename T>
+static int launch_rowstream(const RowStreamParams& p, int depth, int mode, int G, size_t lds, hipStream_t s) {
+  const int mm = rs_padded_rows(p.M);
+#define MSGL_RS(MM_, D_, MODE_) \
+  if (mm == MM_ && depth == D_ && mode == MODE_) return launch_rowstream_t<T, MM_, D_, MODE_>(p, G, lds, s)
+#define MSGL_RS_M(D_, MODE_) \
+  MSGL_RS(1, D_, MODE_); MSGL_RS(2, D_, MODE_); MSGL_RS(4, D_, MODE_); MSGL_RS(8, D_, MODE_)
+  MSGL_RS_M(8, kRsPlain); MSGL_RS_M(16, kRsPlain);
+  MSGL_RS_M(8, kRsSiluHalves); MSGL_RS_M(16, kRsSiluHalves);
+  MSGL_RS_M(8, kRsSiluIlv); MSGL_RS_M(16, kRsSiluIlv);
+  MSGL_RS(1, 8, kRsAddNorm); MSGL_RS(2, 8, kRsAddNorm); MSGL_RS(4, 8, kRsAddNorm);
+  MSGL_RS(1, 16, kRsAddNorm); MSGL_RS(2, 16, kRsAddNorm); MSGL_RS(4, 16, kRsAddNorm);
+#undef MSGL_RS_M
+#undef MSGL_RS
+  set_error("rowstream_gemm_nt: no kernel for M = %d, depth %d, mode %d", p.M, depth, mode);
+  return MSGL_EINVAL;
+}
+
+static int rs_unsupported_reason(int M, int N, int K, int mode, const char** why) {
+  const int G = device_cu_count() > 0 ? device_cu_count() : 256;
+  *why = nullptr;
+  if (M < 1 || M > 8) *why = "M outside [1, 8]";
+  else if (N < 1) *why = "N < 1";
+  else if (K < kRsUnit || K % kRsUnit) *why = "K must be a multiple of 512";
+  else if (mode < 0 || mode > 3) *why = "mode outside 0..3";
+  else if (mode == kRsAddNorm && (M > 4 || K <= 1024 || K > 8192))
+    *why = "mode 3 (fused add + RMSNorm) needs M <= 4 and 1024 < K <= 8192 (the rows rmsnorm_wide_row_kernel takes)";
+  else if (rs_lds_bytes(M, N, K, G) > kRsLdsBudget) *why = "x and the per-row partial sums do not fit the CU's LDS";
+  return *why ? 1 : 0;
+}
+
+}  // namespace msgl
+
+using namespace msgl;
+
+extern "C" int msgl_rowstream_gemm_supported(int M, int N, int K, int mode) {
+  const char* why;
+  return rs_unsupported_reason(M, N, K, mode, &why) ? 0 : 1;
+}
+
+extern "C" int msgl_rowstream_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx,
+                                      int64_t ldw, int64_t ldo, int dtype, int depth, int mode, const void* res_in,
+                                      void* res_out, const void* gamma, float eps, int64_t ldr_in, int64_t ldr_out,
+                                      void* stream) {
+  MSGL_REQUIRE(out && x && w, "rowstream_gemm_nt: null pointer");
+  const char* why;
+  if (rs_unsupported_reason(M, N, K, mode, &why)) {
+    set_error("rowstream_gemm_nt: M = %d, N = %d, K = %d, mode %d: %s", M, N, K, mode, why);
+    return MSGL_EINVAL;
+  }
+  MSGL_REQUIRE(depth == 8 || depth == 16, "rowstream_gemm_nt: depth %d (8 or 16 units in flight per wave)", depth);
+  const int64_t x_cols = mode == kRsSiluHalves || mode == kRsSiluIlv ? 2ll * K : K;
+  MSGL_REQUIRE(ldx >= x_cols && ldw >= K && ldo >= N && ldx % 8 == 0 && ldw % 8 == 0,
+               "rowstream_gemm_nt: leading dimensions (%lld, %lld, %lld)", (long long)ldx, (long long)ldw, (long long)ldo);
+  MSGL_REQUIRE(aligned16(x) && aligned16(w) && (reinterpret_cast<uintptr_t>(out) & 1u) == 0,
+               "rowstream_gemm_nt: x and w must be 16-byte aligned");
+  RowStreamParams p{};
+  p.out = (uint16_t*)out;
+  p.x = (const uint16_t*)x;
+  p.w = (const uint16_t*)w;
+  p.M = M; p.N = N; p.K = K;
+  p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
+  if (mode == kRsAddNorm) {
+    MSGL_REQUIRE(res_in && res_out && gamma, "rowstream_gemm_nt: mode 3 needs res_in, res_out and the norm weight");
+    MSGL_REQUIRE(res_in != res_out && res_out != x && out != x && out != res_in,
+                 "rowstream_gemm_nt: mode 3: res_out must not alias res_in or x (the other workgroups are still reading them)");
+    MSGL_REQUIRE(aligned16(res_in) && aligned16(res_out) && aligned16(gamma) && ldr_in >= K && ldr_out >= K &&
+                     ldr_in % 8 == 0 && ldr_out % 8 == 0,
+                 "rowstream_gemm_nt: mode 3: residual rows must be 16-byte aligned, strides >= K");
+    p.res_in = (const uint16_t*)res_in;
+    p.res_out = (uint16_t*)res_out;
+    p.gamma = (const uint16_t*)gamma;
+    p.eps = eps;
+    p.ldr_in = ldr_in;
+    p.ldr_out = ldr_out;
+  }
+  const int G = device_cu_count() > 0 ? device_cu_count() : 256;
+  const size_t lds = (size_t)rs_lds_bytes(M, N, K, G);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  if (dtype == MSGL_BF16)
+    rc = launch_rowstream<BF16>(p, depth, mode, G, lds, s);
+  else if (dtype == MSGL_FP16)
+    rc = launch_rowstream<FP16>(p, depth, mode, G, lds, s);
+  else {
+    set_error("rowstream_gemm_nt: unsupported dtype code %d", dtype);
+    return MSGL_EINVAL;
+  }
+  if (rc != MSGL_OK) return rc;
+  MSGL_CHECK_LAUNCH("rowstream_gemm_nt");
+  return MSGL_OK;
+}

@@ -9,21 +9,6 @@
 
 namespace msgl {
 
-template <typename T>
-__device__ __forceinline__ void unpack8(const U4& u, float (&f)[8]) {
-  f[0] = Elem<T>::lo(u.x); f[1] = Elem<T>::hi(u.x);
-  f[2] = Elem<T>::lo(u.y); f[3] = Elem<T>::hi(u.y);
-  f[4] = Elem<T>::lo(u.z); f[5] = Elem<T>::hi(u.z);
-  f[6] = Elem<T>::lo(u.w); f[7] = Elem<T>::hi(u.w);
-}
-template <typename T>
-__device__ __forceinline__ U4 pack8(const float (&f)[8]) {
-  U4 u;
-  u.x = Elem<T>::pack(f[0], f[1]); u.y = Elem<T>::pack(f[2], f[3]);
-  u.z = Elem<T>::pack(f[4], f[5]); u.w = Elem<T>::pack(f[6], f[7]);
-  return u;
-}
-
 // sum over the TPR threads that share a row (TPR = 8, 16, 64 or 256)
 template <int TPR>
 __device__ __forceinline__ float row_sum(float x, float* lds) {

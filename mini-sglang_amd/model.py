@@ -29,6 +29,9 @@ from .kvcache import heads_per_rank
 # MSGL_DISABLE_SLAB_NORM=1: keep the split-K reduce of o_proj / down_proj as its own launch (A/B switch)
 _SLAB_NORM = os.environ.get("MSGL_DISABLE_SLAB_NORM") != "1"
 _FUSE_SILU = os.environ.get("MSGL_DISABLE_FUSED_SILU") != "1"
+# MSGL_DISABLE_ROWSTREAM_FUSE=1: at batches <= 8 keep fused_add_rmsnorm / SiLU.mul as their own launches even where the
+# projection that consumes them is the row-streaming kernel (A/B switch; the results are bit-identical either way)
+_ROWSTREAM_FUSE = os.environ.get("MSGL_DISABLE_ROWSTREAM_FUSE") != "1"
 # all-reduce + residual add + RMSNorm as one peer-to-peer launch (csrc/comm_p2p.hip): OPT-IN.  The only measurement
 # available without a multi-GPU box -- one rank's shard with looped-back collectives, bench.py --rank-shard 4 -- has it
 # SLOWER than the two launches (10.24 vs 9.07 ms per step): the kernel keeps the few dozen blocks its flag barriers want,
@@ -327,14 +330,36 @@ class DenseDecoder:
         x = self.comm.all_reduce(x)
         residual: Optional[torch.Tensor] = None
         normed_ahead = False  # the previous layer's down_proj already ran this layer's input norm (row_parallel_norm)
+        # Batches <= 8 (tp = 1): where a projection's plan is the row-streaming kernel (csrc/gemm_rowstream.hip) the row
+        # kernel in front of it rides in that kernel's staging pass -- fused_add_rmsnorm in front of qkv / gate_up / lm_head
+        # (`pending` = the previous projection's output still waiting for its add + norm; the new residual goes to the
+        # other one of two buffers, every workgroup is still reading the old one), SiLU.mul in front of down_proj.  Same bits.
+        T = x.shape[0]
+        rs_on = _ROWSTREAM_FUSE and self.fused and self.tp_size == 1 and T <= ops.ROWSTREAM_MAX_M
+        pending: Optional[torch.Tensor] = None
+        spare: Optional[torch.Tensor] = None
+
+        def norm_into(w: torch.Tensor, y: torch.Tensor, norm_w: torch.Tensor, depth: int, out=None) -> torch.Tensor:
+            nonlocal residual, spare
+            if spare is None:
+                spare = torch.empty_like(residual)
+            r = ops.rowstream_linear(y, w, depth, out=out, mode=ops.ROWSTREAM_ADD_NORM, res_in=residual, res_out=spare,
+                                     gamma=norm_w, eps=cfg.rms_norm_eps)
+            residual, spare = spare, residual
+            return r
+
         for li, lw in enumerate(self.layers):
             if residual is None:  # P/layers/norm.py:35-36
                 residual = x
                 x = fi.rmsnorm(x, lw.input_norm, cfg.rms_norm_eps)
             elif not normed_ahead:
                 fi.fused_add_rmsnorm(x, residual, lw.input_norm, cfg.rms_norm_eps)
-            # a k-sliced full-batch plan leaves the qkv projection's reduce to the fused norm / RoPE / store pass
-            qkv, slabs = ops.linear_slabs(x, lw.qkv) if self.fused and _SLAB_NORM else (ops.linear(x, lw.qkv), None)
+            if pending is not None:  # the previous layer's down_proj output: add + input norm in the qkv launch
+                qkv, slabs = norm_into(lw.qkv, pending, lw.input_norm, ops.rowstream_planned(T, lw.qkv, ops.ROWSTREAM_ADD_NORM)), None
+                pending = None
+            else:
+                # a k-sliced full-batch plan leaves the qkv projection's reduce to the fused norm / RoPE / store pass
+                qkv, slabs = ops.linear_slabs(x, lw.qkv) if self.fused and _SLAB_NORM else (ops.linear(x, lw.qkv), None)
             q, k, v = qkv.split([self.q_dim, self.kv_dim, self.kv_dim], dim=-1)
             if self.fused:
                 kc, vc = kv.k_cache(li), kv.v_cache(li)
@@ -354,17 +379,41 @@ class DenseDecoder:
                 fi.apply_rope_with_cos_sin_cache_inplace(positions=batch.positions, query=q, key=k, head_size=D,
                                                          cos_sin_cache=self.cos_sin)
                 o = backend.forward(q.view(-1, self.hq, D), k, v, li, batch)
-            x = self.row_parallel_norm(o.view(-1, self.q_dim), lw.o, residual, lw.post_norm)
-            if self.gate_up_ilv:  # projection + SiLU.mul: one launch where planned (P/models/utils.py:45-51)
-                y = ops.linear_silu(x, lw.gate_up)
-            else:
-                y = fi.silu_and_mul(ops.linear(x, lw.gate_up))
             # down_proj feeds the NEXT layer's input norm (or the final norm): its all-reduce / slab reduce joins that norm
-            nxt = self.layers[li + 1].input_norm if li + 1 < len(self.layers) else self.final_norm
-            x = self.row_parallel_norm(y, lw.down, residual, nxt)
+            last = li + 1 == len(self.layers)
+            nxt = self.final_norm if last else self.layers[li + 1].input_norm
+            d_gu = ops.rowstream_planned(T, lw.gate_up, ops.ROWSTREAM_ADD_NORM) if rs_on else 0
+            act_mode = ops.ROWSTREAM_SILU_INTERLEAVED if self.gate_up_ilv else ops.ROWSTREAM_SILU
+            d_dn = ops.rowstream_planned(T, lw.down, act_mode) if rs_on else 0
+            if d_gu:  # o_proj, then post-attention add + norm inside the gate_up launch
+                gu = norm_into(lw.gate_up, ops.linear(o.view(-1, self.q_dim), lw.o), lw.post_norm, d_gu)
+            else:
+                x = self.row_parallel_norm(o.view(-1, self.q_dim), lw.o, residual, lw.post_norm)
+                gu = None
+            if d_dn:  # SiLU.mul while down_proj stages its input
+                if gu is None:
+                    gu = ops.linear(x, lw.gate_up)
+                x = ops.rowstream_linear(gu, lw.down, d_dn, mode=act_mode)
+                # the next consumer (next layer's qkv, or the LM head of a decode batch) takes the add + norm if it can
+                nxt_w = self.lm_head if last else self.layers[li + 1].qkv
+                if (not last or not batch.is_prefill) and ops.rowstream_planned(T, nxt_w, ops.ROWSTREAM_ADD_NORM):
+                    pending = x
+                else:
+                    fi.fused_add_rmsnorm(x, residual, nxt, cfg.rms_norm_eps)
+            else:
+                if gu is not None:
+                    y = ops.silu_and_mul_interleaved(gu) if self.gate_up_ilv else fi.silu_and_mul(gu)
+                elif self.gate_up_ilv:  # projection + SiLU.mul: one launch where planned (P/models/utils.py:45-51)
+                    y = ops.linear_silu(x, lw.gate_up)
+                else:
+                    y = fi.silu_and_mul(ops.linear(x, lw.gate_up))
+                x = self.row_parallel_norm(y, lw.down, residual, nxt)
             normed_ahead = True
         # LM head (P/layers/embedding.py:88-110)
         bs = batch.size
+        if pending is not None:  # decode batch: the final add + norm inside the LM head's launch
+            out = logits_out if logits_out is not None and logits_out.shape == (T, self.lm_head.shape[0]) else None
+            return norm_into(self.lm_head, pending, self.final_norm, ops.rowstream_planned(T, self.lm_head, ops.ROWSTREAM_ADD_NORM), out)
         if batch.is_prefill:
             x = x[batch.attn_metadata.get_last_indices(bs)].contiguous()
         if self.tp_size == 1:

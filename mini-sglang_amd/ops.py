@@ -7,6 +7,7 @@ function does (e.g. `indexing` output), none synchronises.
 """
 from __future__ import annotations
 
+import functools
 import os
 from typing import Optional, Tuple
 
@@ -500,9 +501,67 @@ def skinny_supported(M: int, N: int, K: int) -> bool:
     return 1 <= M <= SKINNY_MAX_M and N % 16 == 0 and K % 64 == 0
 
 
+ROWSTREAM_MAX_M = 8
+ROWSTREAM_PLAIN, ROWSTREAM_SILU, ROWSTREAM_SILU_INTERLEAVED, ROWSTREAM_ADD_NORM = 0, 1, 2, 3
+
+
+@functools.lru_cache(maxsize=None)
+def rowstream_supported(M: int, N: int, K: int, mode: int = 0) -> bool:
+    """Whether msgl_rowstream_gemm_nt takes this shape (M <= 8, K % 512 == 0, x + partial sums within the CU's LDS;
+    mode 3: M <= 4 and a hidden size rmsnorm_wide_row_kernel runs)."""
+    return bool(lib().msgl_rowstream_gemm_supported(M, N, K, mode))
+
+
+def rowstream_linear(x: torch.Tensor, w: torch.Tensor, depth: int = 16, out: Optional[torch.Tensor] = None, mode: int = 0,
+                     res_in: Optional[torch.Tensor] = None, res_out: Optional[torch.Tensor] = None,
+                     gamma: Optional[torch.Tensor] = None, eps: float = 0.0) -> torch.Tensor:
+    """out[M, N] = f(x) @ w[N, K]^T by msgl_rowstream_gemm_nt (M <= 8; csrc/gemm_rowstream.hip): the weight matrix as
+    one contiguous stream per CU.  mode 0: f(x) = x [M, K]; 1 / 2: x [M, 2 K] is a gate_up output (halves / interleaved)
+    and f = silu(gate) * up; 3: f = fused_add_rmsnorm(x, res_in) with the new residual written to res_out."""
+    _need_cuda(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.dtype == w.dtype and x.stride(1) == 1 and w.stride(1) == 1
+    M, N, K = x.shape[0], w.shape[0], w.shape[1]
+    assert x.shape[1] == (2 * K if mode in (ROWSTREAM_SILU, ROWSTREAM_SILU_INTERLEAVED) else K), (x.shape, w.shape, mode)
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == x.dtype and out.is_cuda
+    _no_pending_slabs(x.device)
+    if mode == ROWSTREAM_ADD_NORM:
+        assert res_in is not None and res_out is not None and gamma is not None
+        _need_cuda(res_in, res_out, gamma)
+        assert res_in.shape == x.shape and res_out.shape == x.shape and res_in.stride(1) == 1 and res_out.stride(1) == 1
+        assert res_in.dtype == x.dtype and res_out.dtype == x.dtype and gamma.dtype == x.dtype and gamma.numel() == K
+        extra = (res_in.data_ptr(), res_out.data_ptr(), gamma.data_ptr(), float(eps), res_in.stride(0), res_out.stride(0))
+    else:
+        extra = (None, None, None, 0.0, 0, 0)
+    check(
+        lib().msgl_rowstream_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
+                                     out.stride(0), _dt(x), depth, mode, *extra, _stream()),
+        "rowstream_gemm_nt",
+    )
+    return out
+
+
+def rowstream_planned(M: int, w: torch.Tensor, mode: int = 0) -> int:
+    """Ring depth (8 / 16) if the plan of `linear(x [M, K], w)` is the row-streaming kernel and that kernel also takes the
+    shape with staging `mode`, else 0: the decoder layer folds a neighbouring row kernel into the projection only where
+    the projection already is this kernel (the fused launch then costs what the plain one does)."""
+    if M > ROWSTREAM_MAX_M or not _SKINNY_PLAN:
+        return 0
+    N, K = w.shape
+    key = (w.device.index or 0, M, N, K, K, w.stride(0), _dt(w))
+    plan = _SKINNY_PLAN.get(key)
+    if not plan or plan[0] != 0 or _WSTREAM_PLAN.get(key) or not rowstream_supported(M, N, K, mode):
+        return 0
+    return plan[1]
+
+
 def skinny_linear(x: torch.Tensor, w: torch.Tensor, slices: int, out: Optional[torch.Tensor] = None,
                   row_tiles: int = 1) -> torch.Tensor:
-    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_skinny_gemm_nt (M <= 64)."""
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_skinny_gemm_nt (M <= 64).  A plan (0, depth) names the row-streaming
+    kernel of the same family (M <= 8, rowstream_linear): the plan tables keep one (a, b) pair per shape."""
+    if slices == 0:
+        return rowstream_linear(x, w, row_tiles, out)
     out, M, N, K = _gemm_args(x, w, out)
     check(
         lib().msgl_skinny_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
@@ -559,6 +618,8 @@ def skinny_candidates(M: int, N: int, K: int):
             continue
         cap = min(16 if mt * nt <= 2 else 8 if mt * nt <= 8 else 4, K // 64)
         out += [(sl, nt) for sl in (1, 2, 4, 8, 16) if sl <= cap]
+    if M <= ROWSTREAM_MAX_M and os.environ.get("MSGL_DISABLE_ROWSTREAM") != "1" and rowstream_supported(M, N, K):
+        out += [(0, 8), (0, 16)]  # the row-streaming kernel, 8 / 16 loads in flight per lane
     return out
 
 

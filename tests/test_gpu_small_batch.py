@@ -1,0 +1,131 @@
+"""The smallest decode batches (1 .. 4 sequences) of a Qwen3-14B-dimension decoder with every projection on the
+row-streaming kernel (csrc/gemm_rowstream.hip) and the layer's row kernels folded into its staging pass
+(model.DenseDecoder.forward: fused_add_rmsnorm in front of qkv / gate_up / lm_head, SiLU.mul in front of down_proj):
+
+  * the folded forward equals the unfolded one BIT FOR BIT (logits and KV pool), eager and under graph replay;
+  * both are the reference's composition (P/models/qwen3.py:18-81) within the bf16 band of tests/test_gpu_model_14b.py
+    against oracle/ref_model.py, teacher-forced on the recorded batches;
+  * the folding really happens: no fused_add_rmsnorm / activation launch is left in a decode forward.
+"""
+import random
+
+import pytest
+import torch
+
+import parity_stats
+from oracle import ref_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(layers):
+    from mini_sglang_amd.model import PRESETS, ModelConfig
+
+    m = PRESETS["qwen3-14b"]
+    return ModelConfig(layers, m.num_qo_heads, m.num_kv_heads, m.head_dim, m.hidden_size, m.vocab_size,
+                       m.intermediate_size, name="Qwen3-14B dims, reduced depth")
+
+
+def _plan_rowstream(ops, model, batch_sizes, depth):
+    """What the search does when the row-streaming kernel wins a shape: record (0, depth) for it."""
+    from mini_sglang_amd import _lib
+
+    ws = [model.lm_head] + [w for lw in model.layers for w in (lw.qkv, lw.o, lw.gate_up, lw.down)]
+    n = 0
+    for M in batch_sizes:
+        for w in ws:
+            N, K = w.shape
+            if ops.rowstream_supported(M, N, K):
+                ops._SKINNY_PLAN[(w.device.index or 0, M, N, K, K, w.stride(0), _lib.BF16)] = (0, depth)
+                n += 1
+    return n
+
+
+def test_small_decode_batches_rowstream_folded_equals_unfolded_and_matches_oracle(dev, monkeypatch):
+    from mini_sglang_amd import flashinfer_compat as fi
+    from mini_sglang_amd import model as model_mod
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.offline import OfflineRunner
+    from replay_util import record_offline_runner, replay_forward
+
+    layers = 2
+    m = _cfg(layers)
+    cfg = EngineConfig(model=m, dtype=torch.bfloat16, max_running_req=4, page_size=16, cuda_graph_bs=[1, 2, 4],
+                       max_seq_len_override=512, num_page_override=256, seed=7, gemm_tune="off")
+    eng = Engine(cfg, dev)
+    try:
+        assert not ops._SKINNY_PLAN
+        rnd = random.Random(3)
+        eng.kv_cache.pool.zero_()
+        rec = []
+        runner = OfflineRunner(eng, max_extend_tokens=64, seed=1)
+        record_offline_runner(runner, eng, rec)
+        for n_req in (3, 1, 2):  # decode batches of 3 (padded to the 4-graph), 1, 2; the prefills carry 3 .. 40 tokens
+            prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(1, 14))] for _ in range(n_req)]
+            runner.generate(prompts, [SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True) for _ in prompts])
+        decodes = [f for f in rec if f["phase"] == "decode"]
+        assert {f["size"] for f in decodes} == {1, 2, 3} and all(f["graph"] for f in decodes)
+
+        def run_all(fold: bool):
+            """Every recorded forward again (KV pool from zero), decode graphs re-captured with the plans in force."""
+            monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", fold)
+            eng.kv_cache.pool.zero_()
+            for bs in (4, 2, 1):
+                eng.graph_runner.capture(bs)
+            out = [replay_forward(eng, f).float().cpu() for f in rec]
+            torch.cuda.synchronize()
+            return out, eng.kv_cache.pool.clone()
+
+        base, _ = run_all(False)  # library GEMMs (no plans), separate row kernels: the recorded run itself
+        for f, lg in zip(rec, base):
+            assert torch.equal(lg, f["logits"])
+        planned = _plan_rowstream(ops, eng.model, (1, 2, 3, 4), 16)
+        assert planned == 4 * (1 + 4 * layers)
+        unfolded, unfolded_pool = run_all(False)
+        folded, folded_pool = run_all(True)
+        # count the row-kernel launches of one eager decode forward, folded and not
+        calls = {"norm": 0, "act": 0}
+        real_norm, real_act = fi.fused_add_rmsnorm, ops.silu_and_mul_interleaved
+        monkeypatch.setattr(fi, "fused_add_rmsnorm", lambda *a, **k: (calls.__setitem__("norm", calls["norm"] + 1), real_norm(*a, **k))[1])
+        monkeypatch.setattr(ops, "silu_and_mul_interleaved", lambda *a, **k: (calls.__setitem__("act", calls["act"] + 1), real_act(*a, **k))[1])
+        monkeypatch.setattr(eng.graph_runner, "can_use_cuda_graph", lambda batch: False)
+        # the LAST recorded forward: its pages are still what they were (earlier requests' pages have been recycled since)
+        assert rec[-1] is decodes[-1]
+        one = dict(decodes[-1], graph=False)
+        monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", True)
+        eager_folded = replay_forward(eng, one).float().cpu()
+        assert calls == {"norm": 0, "act": 0}, calls
+        monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", False)
+        eager_unfolded = replay_forward(eng, one).float().cpu()
+        assert calls["norm"] == 2 * layers and calls["act"] + int(not eng.model.gate_up_ilv) * layers == layers, calls
+        assert torch.equal(eager_folded, eager_unfolded)
+        for i, (f, a, b) in enumerate(zip(rec, unfolded, folded)):
+            assert torch.equal(a, b), (i, f["phase"], f["size"])
+        assert torch.equal(unfolded_pool, folded_pool)
+        assert torch.equal(eager_folded, folded[-1])  # eager == graph replay
+
+        # teacher-forced against the oracle (same band as the full-batch test at these dims)
+        w = ref_model.weights_from_device_model(eng.model)
+        table = eng.page_table.cpu()
+        slots = eng.kv_cache.pool.shape[2] * eng.kv_cache.pool.shape[3]
+        kp = [torch.zeros((slots, m.num_kv_heads, m.head_dim), dtype=torch.bfloat16) for _ in range(layers)]
+        vp = [torch.zeros_like(k) for k in kp]
+        stats, stats_base = {}, {}
+        for i, f in enumerate(rec):
+            k_lens, q_lens = f["device_lens"], [d - c for d, c in zip(f["device_lens"], f["cached_lens"])]
+            tb = torch.zeros_like(table)  # pages are recycled between the three generate() calls: this forward's rows
+            tb[torch.tensor(f["rows"]), : f["table"].shape[1]] = f["table"]
+            want = ref_model.forward(m, w, f["input_ids"], f["positions"], f["out_loc"], kp, vp, tb, f["rows"], k_lens, q_lens,
+                                     f["phase"] == "prefill").float()[: f["size"]]
+            st = parity_stats.logit_error_stats(folded[i], want)
+            stats = parity_stats.merge_stats(stats, st)
+            stats_base = parity_stats.merge_stats(stats_base, parity_stats.logit_error_stats(base[i], want))
+            assert st["max_abs"] <= 1.5e-1, (i, parity_stats.fmt(st))
+        print(f"\n[14B dims, {layers} layers, batches of 1-3] row-streaming + folded: {parity_stats.fmt(stats)}")
+        print(f"[14B dims, {layers} layers, batches of 1-3] library GEMMs, separate row kernels: {parity_stats.fmt(stats_base)}")
+        assert stats["mean_abs"] <= max(2e-2, 1.25 * stats_base["mean_abs"])
+    finally:
+        eng.shutdown()
+        ops.reset_gemm_plans()
