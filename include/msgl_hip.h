@@ -306,10 +306,13 @@ int msgl_skinny_gemm_silu_nt(void* out, const void* x, const void* w, int M, int
  *      output: msgl_fused_add_rmsnorm -- P/layers/norm.py:33-38 -- followed by mode 0, bit for bit; M <= 4,
  *      1024 < K <= 8192; res_out must be a different buffer from res_in and x: every workgroup reads them while
  *      workgroup 0 writes the new residual)
- * res_in / res_out / gamma / eps / ldr_* are read in mode 3 only (pass NULL / 0 otherwise). */
-int msgl_rowstream_gemm_supported(int M, int N, int K, int mode);
+ * res_in / res_out / gamma / eps / ldr_* are read in mode 3 only (pass NULL / 0 otherwise).
+ * `variant` 0: dot products on the vector units, units of one row x 512 k (K % 512 == 0; the fastest form at M = 1);
+ * variant 1: on the matrix cores (v_mfma_f32_4x4x4_16b), units of four rows x 128 k, one LDS read of x per four staged
+ * rows whatever M is (N % 4 == 0, K % 128 == 0; for M = 2 .. 8).  The two variants add in different orders. */
+int msgl_rowstream_gemm_supported(int M, int N, int K, int mode, int variant);
 int msgl_rowstream_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
-                           int64_t ldo, int dtype, int depth, int mode, const void* res_in, void* res_out,
+                           int64_t ldo, int dtype, int depth, int mode, int variant, const void* res_in, void* res_out,
                            const void* gamma, float eps, int64_t ldr_in, int64_t ldr_out, void* stream);
 
 /* Same product for mid-size decode batches (1 <= M <= 256; meant for 32 < M): the 8 waves of a workgroup

@@ -72,8 +72,8 @@ HIP_SIGNATURES = {
     "msgl_sample_from_logits": (_i, [_p, _p, _p, _l, _l, _l, _i, _u64, _u64, _p]),
     "msgl_skinny_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
     "msgl_skinny_gemm_silu_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p]),
-    "msgl_rowstream_gemm_supported": (_i, [_i, _i, _i, _i]),
-    "msgl_rowstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _p, _p, _f, _l, _l, _p]),
+    "msgl_rowstream_gemm_supported": (_i, [_i, _i, _i, _i, _i]),
+    "msgl_rowstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _p, _p, _f, _l, _l, _p]),
     "msgl_wstream_gemm_workspace_bytes": (_l, [_i, _i, _i]),
     "msgl_wstream_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _l, _p]),
     "msgl_wstream_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),

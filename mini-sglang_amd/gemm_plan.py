@@ -67,12 +67,17 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
             r = ops.gemm_tune(x, ws, max_candidates=cands[bs], iters=8)
             r["name"] = name
             if bs <= ops.SKINNY_MAX_M:  # hand-written weight-streaming kernel vs the library's best
-                sk = ops.skinny_tune(x, ws, r["best_us"])
+                # flags["fold"]: the row kernel the caller folds into this projection where the row-streaming kernel is planned
+                fold = {"norm": ops.ROWSTREAM_ADD_NORM, "act": ops.ROWSTREAM_SILU, "act_interleaved": ops.ROWSTREAM_SILU_INTERLEAVED}.get(flags.get("fold"))
+                if flags.get("fold", "").startswith("act") and bs > 1:
+                    fold = None  # SiLU.mul is folded at one row only (model.DenseDecoder.forward)
+                sk = ops.skinny_tune(x, ws, r["best_us"], fold_mode=fold)
                 r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
                          skinny_used=sk["used"])
                 if sk["used"]:
                     r["library_best_us"], r["best_us"] = r["best_us"], sk["skinny_us"]
-                    r["kernel"] = f"msgl::skinny_gemm_kernel[slices {sk['slices']}, row tiles {sk['row_tiles']}]"
+                    r["kernel"] = (f"msgl::rowstream{'4' if sk['slices'] else ''}_gemm_kernel[{sk['row_tiles']} loads in flight per lane]" if sk["slices"] <= 0 else
+                                   f"msgl::skinny_gemm_kernel[slices {sk['slices']}, row tiles {sk['row_tiles']}]")
             if 32 < bs <= ops.WSTREAM_MAX_M and name != "lm_head":  # LDS-shared weight-streaming kernel
                 wsr = ops.wstream_tune(x, ws, r["best_us"])
                 r.update(wstream_us=wsr["wstream_us"], wstream_row_tiles=wsr["row_tiles"],

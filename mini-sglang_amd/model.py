@@ -260,9 +260,13 @@ class DenseDecoder:
         """(name, same-shaped weights of up to 8 layers, K) of the five projection shapes."""
         step = max(1, len(self.layers) // 8)
         pick = self.layers[::step][:8]
-        return [("qkv", [l.qkv for l in pick], self.cfg.hidden_size), ("o", [l.o for l in pick], self.q_dim),
-                ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size, {"silu_interleaved": self.gate_up_ilv}),
-                ("down", [l.down for l in pick], self.inter), ("lm_head", [self.lm_head], self.cfg.hidden_size)]
+        # "fold": the row kernel forward() folds into the projection where the row-streaming kernel is planned (batches <= 8)
+        fold = self.fused and self.tp_size == 1 and _ROWSTREAM_FUSE
+        norm = {"fold": "norm"} if fold else {}
+        act = {"fold": "act_interleaved" if self.gate_up_ilv else "act"} if fold else {}
+        return [("qkv", [l.qkv for l in pick], self.cfg.hidden_size, norm), ("o", [l.o for l in pick], self.q_dim),
+                ("gate_up", [l.gate_up for l in pick], self.cfg.hidden_size, {"silu_interleaved": self.gate_up_ilv, **norm}),
+                ("down", [l.down for l in pick], self.inter, act), ("lm_head", [self.lm_head], self.cfg.hidden_size, norm)]
 
     def tune_gemms(self, batch_sizes: List[int], mode: str = "heuristic", log=None, prefill_tokens=()) -> List[dict]:
         from .gemm_plan import tune_prefill_gemms, tune_projection_gemms
@@ -339,12 +343,12 @@ class DenseDecoder:
         pending: Optional[torch.Tensor] = None
         spare: Optional[torch.Tensor] = None
 
-        def norm_into(w: torch.Tensor, y: torch.Tensor, norm_w: torch.Tensor, depth: int, out=None) -> torch.Tensor:
+        def norm_into(w: torch.Tensor, y: torch.Tensor, norm_w: torch.Tensor, plan, out=None) -> torch.Tensor:
             nonlocal residual, spare
             if spare is None:
                 spare = torch.empty_like(residual)
-            r = ops.rowstream_linear(y, w, depth, out=out, mode=ops.ROWSTREAM_ADD_NORM, res_in=residual, res_out=spare,
-                                     gamma=norm_w, eps=cfg.rms_norm_eps)
+            r = ops.rowstream_linear(y, w, plan[0], out=out, mode=ops.ROWSTREAM_ADD_NORM, res_in=residual, res_out=spare,
+                                     gamma=norm_w, eps=cfg.rms_norm_eps, variant=plan[1])
             residual, spare = spare, residual
             return r
 
@@ -382,24 +386,23 @@ class DenseDecoder:
             # down_proj feeds the NEXT layer's input norm (or the final norm): its all-reduce / slab reduce joins that norm
             last = li + 1 == len(self.layers)
             nxt = self.final_norm if last else self.layers[li + 1].input_norm
-            d_gu = ops.rowstream_planned(T, lw.gate_up, ops.ROWSTREAM_ADD_NORM) if rs_on else 0
+            d_gu = ops.rowstream_planned(T, lw.gate_up, ops.ROWSTREAM_ADD_NORM) if rs_on else None
             act_mode = ops.ROWSTREAM_SILU_INTERLEAVED if self.gate_up_ilv else ops.ROWSTREAM_SILU
-            d_dn = ops.rowstream_planned(T, lw.down, act_mode) if rs_on else 0
+            # SiLU.mul in the staging pass pays at one row only (M = 4: 45 vs 41 us for the pair, profiles/r04_rowstream_bench.json)
+            d_dn = ops.rowstream_planned(T, lw.down, act_mode) if rs_on and T == 1 else None
             if d_gu:  # o_proj, then post-attention add + norm inside the gate_up launch
                 gu = norm_into(lw.gate_up, ops.linear(o.view(-1, self.q_dim), lw.o), lw.post_norm, d_gu)
             else:
                 x = self.row_parallel_norm(o.view(-1, self.q_dim), lw.o, residual, lw.post_norm)
                 gu = None
+            # the next consumer of the residual stream (next layer's qkv, or the LM head of a decode batch) takes down_proj's
+            # add + norm into its own launch if it can
+            fold_next = (ops.rowstream_planned(T, self.lm_head if last else self.layers[li + 1].qkv, ops.ROWSTREAM_ADD_NORM)
+                         if rs_on and not (last and batch.is_prefill) else None)
             if d_dn:  # SiLU.mul while down_proj stages its input
                 if gu is None:
                     gu = ops.linear(x, lw.gate_up)
-                x = ops.rowstream_linear(gu, lw.down, d_dn, mode=act_mode)
-                # the next consumer (next layer's qkv, or the LM head of a decode batch) takes the add + norm if it can
-                nxt_w = self.lm_head if last else self.layers[li + 1].qkv
-                if (not last or not batch.is_prefill) and ops.rowstream_planned(T, nxt_w, ops.ROWSTREAM_ADD_NORM):
-                    pending = x
-                else:
-                    fi.fused_add_rmsnorm(x, residual, nxt, cfg.rms_norm_eps)
+                x = ops.rowstream_linear(gu, lw.down, d_dn[0], mode=act_mode, variant=d_dn[1])
             else:
                 if gu is not None:
                     y = ops.silu_and_mul_interleaved(gu) if self.gate_up_ilv else fi.silu_and_mul(gu)
@@ -407,7 +410,11 @@ class DenseDecoder:
                     y = ops.linear_silu(x, lw.gate_up)
                 else:
                     y = fi.silu_and_mul(ops.linear(x, lw.gate_up))
-                x = self.row_parallel_norm(y, lw.down, residual, nxt)
+                x = ops.linear(y, lw.down) if fold_next else self.row_parallel_norm(y, lw.down, residual, nxt)
+            if fold_next:
+                pending = x
+            elif d_dn:
+                fi.fused_add_rmsnorm(x, residual, nxt, cfg.rms_norm_eps)
             normed_ahead = True
         # LM head (P/layers/embedding.py:88-110)
         bs = batch.size

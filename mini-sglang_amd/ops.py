@@ -505,19 +505,23 @@ ROWSTREAM_MAX_M = 8
 ROWSTREAM_PLAIN, ROWSTREAM_SILU, ROWSTREAM_SILU_INTERLEAVED, ROWSTREAM_ADD_NORM = 0, 1, 2, 3
 
 
+ROWSTREAM_VECTOR, ROWSTREAM_MATRIX = 0, 1  # variant: dot products on the vector units / on the matrix cores (4x4x4 MFMA)
+
+
 @functools.lru_cache(maxsize=None)
-def rowstream_supported(M: int, N: int, K: int, mode: int = 0) -> bool:
-    """Whether msgl_rowstream_gemm_nt takes this shape (M <= 8, K % 512 == 0, x + partial sums within the CU's LDS;
-    mode 3: M <= 4 and a hidden size rmsnorm_wide_row_kernel runs)."""
-    return bool(lib().msgl_rowstream_gemm_supported(M, N, K, mode))
+def rowstream_supported(M: int, N: int, K: int, mode: int = 0, variant: int = 0) -> bool:
+    """Whether msgl_rowstream_gemm_nt takes this shape (M <= 8; variant 0: K % 512 == 0, variant 1: K % 128 == 0 and
+    N % 4 == 0; x + partial sums within the CU's LDS; mode 3: M <= 4 and a hidden size rmsnorm_wide_row_kernel runs)."""
+    return bool(lib().msgl_rowstream_gemm_supported(M, N, K, mode, variant))
 
 
 def rowstream_linear(x: torch.Tensor, w: torch.Tensor, depth: int = 16, out: Optional[torch.Tensor] = None, mode: int = 0,
                      res_in: Optional[torch.Tensor] = None, res_out: Optional[torch.Tensor] = None,
-                     gamma: Optional[torch.Tensor] = None, eps: float = 0.0) -> torch.Tensor:
+                     gamma: Optional[torch.Tensor] = None, eps: float = 0.0, variant: int = 0) -> torch.Tensor:
     """out[M, N] = f(x) @ w[N, K]^T by msgl_rowstream_gemm_nt (M <= 8; csrc/gemm_rowstream.hip): the weight matrix as
     one contiguous stream per CU.  mode 0: f(x) = x [M, K]; 1 / 2: x [M, 2 K] is a gate_up output (halves / interleaved)
-    and f = silu(gate) * up; 3: f = fused_add_rmsnorm(x, res_in) with the new residual written to res_out."""
+    and f = silu(gate) * up; 3: f = fused_add_rmsnorm(x, res_in) with the new residual written to res_out.
+    variant 0 / 1: products on the vector units (M = 1) / on the matrix cores (M = 2 .. 8); different summation orders."""
     _need_cuda(x, w)
     assert x.dim() == 2 and w.dim() == 2 and x.dtype == w.dtype and x.stride(1) == 1 and w.stride(1) == 1
     M, N, K = x.shape[0], w.shape[0], w.shape[1]
@@ -536,32 +540,33 @@ def rowstream_linear(x: torch.Tensor, w: torch.Tensor, depth: int = 16, out: Opt
         extra = (None, None, None, 0.0, 0, 0)
     check(
         lib().msgl_rowstream_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
-                                     out.stride(0), _dt(x), depth, mode, *extra, _stream()),
+                                     out.stride(0), _dt(x), depth, mode, variant, *extra, _stream()),
         "rowstream_gemm_nt",
     )
     return out
 
 
-def rowstream_planned(M: int, w: torch.Tensor, mode: int = 0) -> int:
-    """Ring depth (8 / 16) if the plan of `linear(x [M, K], w)` is the row-streaming kernel and that kernel also takes the
-    shape with staging `mode`, else 0: the decoder layer folds a neighbouring row kernel into the projection only where
-    the projection already is this kernel (the fused launch then costs what the plain one does)."""
+def rowstream_planned(M: int, w: torch.Tensor, mode: int = 0):
+    """(ring depth, variant) if the plan of `linear(x [M, K], w)` is the row-streaming kernel and that kernel also takes
+    the shape with staging `mode`, else None: the decoder layer folds a neighbouring row kernel into the projection only
+    where the projection already is this kernel (the folded launch then costs what the plain one does)."""
     if M > ROWSTREAM_MAX_M or not _SKINNY_PLAN:
-        return 0
+        return None
     N, K = w.shape
     key = (w.device.index or 0, M, N, K, K, w.stride(0), _dt(w))
     plan = _SKINNY_PLAN.get(key)
-    if not plan or plan[0] != 0 or _WSTREAM_PLAN.get(key) or not rowstream_supported(M, N, K, mode):
-        return 0
-    return plan[1]
+    if not plan or plan[0] > 0 or _WSTREAM_PLAN.get(key) or not rowstream_supported(M, N, K, mode, -plan[0]):
+        return None
+    return plan[1], -plan[0]
 
 
 def skinny_linear(x: torch.Tensor, w: torch.Tensor, slices: int, out: Optional[torch.Tensor] = None,
                   row_tiles: int = 1) -> torch.Tensor:
-    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_skinny_gemm_nt (M <= 64).  A plan (0, depth) names the row-streaming
-    kernel of the same family (M <= 8, rowstream_linear): the plan tables keep one (a, b) pair per shape."""
-    if slices == 0:
-        return rowstream_linear(x, w, row_tiles, out)
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_skinny_gemm_nt (M <= 64).  A plan (0, depth) / (-1, depth) names the
+    row-streaming kernel of the same family (M <= 8, rowstream_linear, variant 0 / 1): the plan tables keep one (a, b) pair
+    per shape."""
+    if slices <= 0:
+        return rowstream_linear(x, w, row_tiles, out, variant=-slices)
     out, M, N, K = _gemm_args(x, w, out)
     check(
         lib().msgl_skinny_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0),
@@ -618,14 +623,24 @@ def skinny_candidates(M: int, N: int, K: int):
             continue
         cap = min(16 if mt * nt <= 2 else 8 if mt * nt <= 8 else 4, K // 64)
         out += [(sl, nt) for sl in (1, 2, 4, 8, 16) if sl <= cap]
-    if M <= ROWSTREAM_MAX_M and os.environ.get("MSGL_DISABLE_ROWSTREAM") != "1" and rowstream_supported(M, N, K):
-        out += [(0, 8), (0, 16)]  # the row-streaming kernel, 8 / 16 loads in flight per lane
+    if M <= ROWSTREAM_MAX_M and os.environ.get("MSGL_DISABLE_ROWSTREAM") != "1":
+        # the row-streaming kernel, 8 / 16 loads in flight per lane: (0, depth) on the vector units, (-1, depth) on the matrix cores
+        out += [(-v, d) for v in (ROWSTREAM_VECTOR, ROWSTREAM_MATRIX) if rowstream_supported(M, N, K, 0, v) for d in (8, 16)]
     return out
 
 
-def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> dict:
-    """Time the weight-streaming kernel over its (k-slices, row tiles) settings on rotating weights (as
-    gemm_tune does) and plan it for this shape if it beats `library_us`.  Synchronises; call before capture."""
+# what a folded row kernel is worth to the step when the projection behind it is the row-streaming kernel: the launch that
+# disappears minus the staging work that appears, measured inside the captured B = 1 step (tools/small_batch_ab.py:
+# 0.8-0.9 us per fold; the search below works on back-to-back times, which also have rowstream qkv 0.7 us behind the
+# matrix-core kernel where the step has it ahead)
+ROWSTREAM_FOLD_BONUS_US = 1.5
+
+
+def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8, fold_mode: Optional[int] = None) -> dict:
+    """Time the weight-streaming kernels over their settings on rotating weights (as gemm_tune does) and plan the best for
+    this shape if it beats `library_us`.  fold_mode: the staging mode (ROWSTREAM_ADD_NORM / ROWSTREAM_SILU*) by which the
+    decoder layer would fold the row kernel in front of this projection if the row-streaming kernel is planned; settings
+    that can are credited ROWSTREAM_FOLD_BONUS_US.  Synchronises; call before capture."""
     weights = list(weights)
     w0 = weights[0]
     M, K = x.shape
@@ -648,11 +663,17 @@ def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8) -> 
             ts.append(e0.elapsed_time(e1) * 1e3 / iters)
         return min(ts)
 
-    ranked = sorted((time_us(sl, nt, 1), sl, nt) for sl, nt in skinny_candidates(M, N, K))
-    best = min((time_us(sl, nt, 3), sl, nt) for _, sl, nt in ranked[:4])  # re-time the best few
-    res.update(skinny_us=best[0], slices=best[1], row_tiles=best[2])
+    def credit(sl):
+        folds = fold_mode is not None and sl <= 0 and rowstream_supported(M, N, K, fold_mode, -sl)
+        return ROWSTREAM_FOLD_BONUS_US if folds else 0.0
+
+    ranked = sorted((time_us(sl, nt, 1) - credit(sl), sl, nt) for sl, nt in skinny_candidates(M, N, K))
+    timed = [(time_us(sl, nt, 3), sl, nt) for _, sl, nt in ranked[:5]]  # re-time the best few
+    best = min(timed, key=lambda t: t[0] - credit(t[1]))
+    res.update(skinny_us=best[0], slices=best[1], row_tiles=best[2], best_plain_us=min(t[0] for t in timed),
+               rowstream_us=min((t[0] for t in timed if t[1] <= 0), default=None))
     key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
-    if best[0] < PLAN_MARGIN * library_us:
+    if best[0] - credit(best[1]) < PLAN_MARGIN * library_us:
         _SKINNY_PLAN[key] = (best[1], best[2])
         res["used"] = True
     else:

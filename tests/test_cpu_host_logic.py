@@ -75,12 +75,12 @@ def test_skinny_gemm_search_space_respects_kernel_limits():
             cands = ops.skinny_candidates(M, N, K)
             assert cands and len(set(cands)) == len(cands)
             for sl, nt in cands:
-                if sl == 0:  # the row-streaming kernel (csrc/gemm_rowstream.hip): (0, loads in flight per lane)
-                    assert M <= 8 and K % 512 == 0 and nt in (8, 16) and ops.rowstream_supported(M, N, K)
+                if sl <= 0:  # the row-streaming kernel (csrc/gemm_rowstream.hip): (-variant, loads in flight per lane)
+                    assert M <= 8 and K % (128 if sl else 512) == 0 and nt in (8, 16) and ops.rowstream_supported(M, N, K, 0, -sl)
                     continue
                 assert N % (16 * nt) == 0 and 1 <= sl <= K // 64
                 assert sl <= (16 if mt * nt <= 2 else 8 if mt * nt <= 8 else 4)
-            assert ((0, 16) in cands) == (M <= 8 and K % 512 == 0)
+            assert ((0, 16) in cands) == (M <= 8 and K % 512 == 0) and ((-1, 8) in cands) == (M <= 8 and K % 128 == 0 and N % 4 == 0)
     assert not ops.skinny_supported(65, 5120, 5120) and not ops.skinny_supported(8, 40, 128)
     assert not ops.skinny_supported(8, 48, 100) and ops.skinny_supported(64, 48, 64)
     # the host-side shape check of the row-streaming kernel: staged x (padded to 1 / 2 / 4 / 8 rows) + [rows per CU][8 waves][rows of x]
@@ -89,7 +89,8 @@ def test_skinny_gemm_search_space_respects_kernel_limits():
     assert ops.rowstream_supported(4, 5120, 17408, ops.ROWSTREAM_SILU_INTERLEAVED) and not ops.rowstream_supported(5, 5120, 17408)
     assert ops.rowstream_supported(4, 7168, 5120, ops.ROWSTREAM_ADD_NORM) and not ops.rowstream_supported(5, 7168, 5120, ops.ROWSTREAM_ADD_NORM)
     assert not ops.rowstream_supported(1, 7168, 1024, ops.ROWSTREAM_ADD_NORM) and not ops.rowstream_supported(1, 64, 576)
-    assert ops.rowstream_planned(1, __import__("torch").zeros((64, 512), dtype=__import__("torch").bfloat16)) == 0  # no plan, no folding
+    assert ops.rowstream_supported(8, 5120, 4352, 0, ops.ROWSTREAM_MATRIX) and not ops.rowstream_supported(8, 5122, 4352, 0, ops.ROWSTREAM_MATRIX)
+    assert ops.rowstream_planned(1, torch.zeros((64, 512), dtype=torch.bfloat16)) is None  # no plan, no folding
     assert ops.linear.__doc__ and not ops._SKINNY_PLAN  # nothing is planned until skinny_tune ran on a GPU
 
 

@@ -37,22 +37,25 @@ SHAPES = [(7168, 5120), (5120, 17408), (34816, 5120), (151936, 5120), (1000, 102
           (10240, 8192), (5120, 25600)]
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
-@pytest.mark.parametrize("N,K", SHAPES)
-def test_rowstream_matches_fp32_reference(ops, dev, M, N, K):
-    if not ops.rowstream_supported(M, N, K):
-        # x (padded to 1 / 2 / 4 / 8 rows) + the per-row wave sums must fit the CU's LDS: the large-K / LM-head shapes at M = 8
-        assert M * K * 2 + (N + 255) // 256 * 32 * M > 100 * 1024
-        with pytest.raises(RuntimeError, match="do not fit"):
+@pytest.mark.parametrize("N,K", SHAPES + [(5120, 4352), (5120, 1280), (8, 128)])
+def test_rowstream_matches_fp32_reference(ops, dev, M, N, K, variant):
+    """variant 0: products on the vector units (units of one row x 512 k); 1: on the matrix cores (four rows x 128 k)."""
+    if not ops.rowstream_supported(M, N, K, 0, variant):
+        why = ("multiple of 512" if K % 512 else "do not fit") if variant == 0 else ("variant 1 needs" if K % 128 or N % 4 else "do not fit")
+        if why == "do not fit":  # x (padded to 1 / 2 / 4 / 8 rows) + the per-row wave sums must fit the CU's LDS
+            assert M * K * 2 + (N + 255) // 256 * 32 * M > 100 * 1024
+        with pytest.raises(RuntimeError, match=why):
             ops.rowstream_linear(torch.zeros((M, K), dtype=torch.bfloat16, device=dev),
-                                 torch.zeros((N, K), dtype=torch.bfloat16, device=dev))
+                                 torch.zeros((N, K), dtype=torch.bfloat16, device=dev), variant=variant)
         return
     g = torch.Generator(device=dev).manual_seed(M * 131 + N + K)
     x = _rand((M, K), g, dev, 0.5, torch.bfloat16)
     w = _rand((N, K), g, dev, 0.05, torch.bfloat16)
-    out16 = ops.rowstream_linear(x, w, 16)
+    out16 = ops.rowstream_linear(x, w, 16, variant=variant)
     _check(out16, _ref(x, w))
-    out8 = ops.rowstream_linear(x, w, 8)
+    out8 = ops.rowstream_linear(x, w, 8, variant=variant)
     assert torch.equal(out8, out16)  # the ring's depth changes what is in flight, not the order of the sums
 
 
@@ -62,10 +65,11 @@ def test_rowstream_fp16_strides_and_untouched_neighbours(ops, dev):
     bigx = _rand((M, 3 * K), g, dev, 0.5, torch.float16)
     bigw = _rand((N, K + 64), g, dev, 0.05, torch.float16)
     x, w = bigx[:, K:2 * K], bigw[:, :K]
-    fused = torch.zeros((M, N + 200), dtype=torch.float16, device=dev)
-    out = ops.rowstream_linear(x, w, 8, out=fused[:, 100:100 + N])
-    _check(out, _ref(x, w))
-    assert fused[:, :100].abs().max().item() == 0 and fused[:, 100 + N:].abs().max().item() == 0
+    for variant, n in ((0, N), (1, N - 1)):  # 777 rows on the vector units, 776 (a multiple of 4) on the matrix cores
+        fused = torch.zeros((M, n + 200), dtype=torch.float16, device=dev)
+        out = ops.rowstream_linear(x, w[:n], 8, out=fused[:, 100:100 + n], variant=variant)
+        _check(out, _ref(x, w[:n]))
+        assert fused[:, :100].abs().max().item() == 0 and fused[:, 100 + n:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -77,18 +81,23 @@ def test_rowstream_silu_staging_equals_activation_then_projection(ops, dev, dtyp
     gu = _rand((M, 2 * inter), g, dev, 1.5, dtype)
     w = _rand((N, inter), g, dev, 0.03, dtype)
     act = ops.silu_and_mul_interleaved(gu) if interleaved else ops.silu_and_mul(gu)
-    want = ops.rowstream_linear(act, w, 16)
     mode = ops.ROWSTREAM_SILU_INTERLEAVED if interleaved else ops.ROWSTREAM_SILU
     before = gu.clone()
-    for depth in (8, 16):
-        got = ops.rowstream_linear(gu, w, depth, mode=mode)
-        assert torch.equal(got, want)
+    for variant in (0, 1):
+        if not ops.rowstream_supported(M, N, inter, mode, variant):
+            assert variant == 1 and N % 4
+            continue
+        want = ops.rowstream_linear(act, w, 16, variant=variant)
+        for depth in (8, 16):
+            got = ops.rowstream_linear(gu, w, depth, mode=mode, variant=variant)
+            assert torch.equal(got, want)
+        _check(want, _ref(act, w))
     assert torch.equal(gu, before)
-    _check(want, _ref(act, w))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,K,N", [(1, 5120, 7168), (2, 5120, 34816), (3, 8192, 10240), (4, 5120, 151936), (4, 1536, 100), (1, 4096, 4096)])
+@pytest.mark.parametrize("M,K,N", [(1, 5120, 7168), (2, 5120, 34816), (3, 8192, 10240), (4, 5120, 151936), (4, 1536, 100), (1, 4096, 4096),
+                                   (2, 1152, 512)])
 def test_rowstream_add_norm_staging_equals_fused_add_rmsnorm_then_projection(ops, dev, dtype, M, K, N):
     """The decoder layer's `x, residual = norm(x, residual); y = proj(x)` (P/models/qwen3.py:36-41) in one launch."""
     g = torch.Generator(device=dev).manual_seed(M + K + N)
@@ -99,18 +108,22 @@ def test_rowstream_add_norm_staging_equals_fused_add_rmsnorm_then_projection(ops
     w = _rand((N, K), g, dev, 0.03, dtype)
     x_ref, res_ref = x.clone(), res.clone()
     ops.fused_add_rmsnorm(x_ref, res_ref, gamma, eps)  # in place: x_ref = normed, res_ref = new residual
-    want = ops.rowstream_linear(x_ref, w, 16)
     x_before, res_before = x.clone(), res.clone()
-    for depth in (8, 16):
-        res_out = torch.full_like(res, float("nan"))
-        got = ops.rowstream_linear(x, w, depth, mode=ops.ROWSTREAM_ADD_NORM, res_in=res, res_out=res_out, gamma=gamma, eps=eps)
-        assert torch.equal(got, want)
-        assert torch.equal(res_out, res_ref)
-    assert torch.equal(x, x_before) and torch.equal(res, res_before)
-    # and the pair against the fp32 statement of the op
     s = x.float() + res.float()
     y = (s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + eps) * gamma.float()).to(dtype)
-    _check(want, _ref(y, w))
+    for variant in (0, 1):
+        if not ops.rowstream_supported(M, N, K, ops.ROWSTREAM_ADD_NORM, variant):
+            assert variant == 0 and K % 512
+            continue
+        want = ops.rowstream_linear(x_ref, w, 16, variant=variant)
+        for depth in (8, 16):
+            res_out = torch.full_like(res, float("nan"))
+            got = ops.rowstream_linear(x, w, depth, mode=ops.ROWSTREAM_ADD_NORM, res_in=res, res_out=res_out, gamma=gamma, eps=eps,
+                                       variant=variant)
+            assert torch.equal(got, want)
+            assert torch.equal(res_out, res_ref)
+        _check(want, _ref(y, w))  # the pair against the fp32 statement of the op
+    assert torch.equal(x, x_before) and torch.equal(res, res_before)
 
 
 def test_rowstream_add_norm_strided_rows(ops, dev):
@@ -123,8 +136,8 @@ def test_rowstream_add_norm_strided_rows(ops, dev):
     keep = bo[:, K:].clone()
     x_ref, res_ref = x.contiguous(), res.contiguous()
     ops.fused_add_rmsnorm(x_ref, res_ref, gamma, 1e-5)
-    got = ops.rowstream_linear(x, w, 16, mode=ops.ROWSTREAM_ADD_NORM, res_in=res, res_out=res_out, gamma=gamma, eps=1e-5)
-    assert torch.equal(got, ops.rowstream_linear(x_ref, w, 16)) and torch.equal(res_out, res_ref)
+    got = ops.rowstream_linear(x, w, 16, mode=ops.ROWSTREAM_ADD_NORM, res_in=res, res_out=res_out, gamma=gamma, eps=1e-5, variant=1)
+    assert torch.equal(got, ops.rowstream_linear(x_ref, w, 16, variant=1)) and torch.equal(res_out, res_ref)
     assert torch.equal(bo[:, K:], keep)
 
 
@@ -159,6 +172,10 @@ def test_rowstream_rejects_what_it_cannot_do(ops, dev):
         ops.rowstream_linear(z(9, 512), z(64, 512))
     with pytest.raises(RuntimeError, match="multiple of 512"):
         ops.rowstream_linear(z(1, 576), z(64, 576))
+    with pytest.raises(RuntimeError, match="variant 1 needs"):
+        ops.rowstream_linear(z(1, 512), z(66, 512), variant=1)
+    with pytest.raises(RuntimeError, match="variant outside"):
+        ops.rowstream_linear(z(1, 512), z(64, 512), variant=2)
     with pytest.raises(RuntimeError, match="depth"):
         ops.rowstream_linear(z(1, 512), z(64, 512), 4)
     with pytest.raises(RuntimeError, match="mode 3"):
@@ -174,13 +191,13 @@ def test_rowstream_rejects_what_it_cannot_do(ops, dev):
 
 def test_skinny_tune_times_the_rowstream_kernel_and_linear_dispatches(ops, dev):
     """The plan search of the small-batch projections (ops.skinny_tune) includes the row-streaming kernel as the settings
-    (0, 8) / (0, 16); whatever wins, ops.linear must then give that kernel's bits."""
+    (0, depth) -- vector units -- and (-1, depth) -- matrix cores; whatever wins, ops.linear must then give that kernel's bits."""
     g = torch.Generator(device=dev).manual_seed(33)
     M, N, K = 1, 5120, 17408
     x = _rand((M, K), g, dev, 0.5, torch.bfloat16)
     ws = [_rand((N, K), g, dev, 0.05, torch.bfloat16) for _ in range(3)]
-    assert (0, 16) in ops.skinny_candidates(M, N, K) and (0, 8) in ops.skinny_candidates(M, N, K)
-    assert (0, 16) not in ops.skinny_candidates(16, N, K)
+    assert {(0, 8), (0, 16), (-1, 8), (-1, 16)} <= set(ops.skinny_candidates(M, N, K))
+    assert not [c for c in ops.skinny_candidates(16, N, K) if c[0] <= 0]
     rep = ops.skinny_tune(x, ws, library_us=1e9)
     assert rep["used"]
     want = ops.skinny_linear(x, ws[0], rep["slices"], None, rep["row_tiles"])

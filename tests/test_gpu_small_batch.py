@@ -5,7 +5,7 @@ row-streaming kernel (csrc/gemm_rowstream.hip) and the layer's row kernels folde
   * the folded forward equals the unfolded one BIT FOR BIT (logits and KV pool), eager and under graph replay;
   * both are the reference's composition (P/models/qwen3.py:18-81) within the bf16 band of tests/test_gpu_model_14b.py
     against oracle/ref_model.py, teacher-forced on the recorded batches;
-  * the folding really happens: no fused_add_rmsnorm / activation launch is left in a decode forward.
+  * the folding really happens: no fused_add_rmsnorm launch is left in a decode forward, and no activation launch at one row.
 """
 import random
 
@@ -26,8 +26,8 @@ def _cfg(layers):
                        m.intermediate_size, name="Qwen3-14B dims, reduced depth")
 
 
-def _plan_rowstream(ops, model, batch_sizes, depth):
-    """What the search does when the row-streaming kernel wins a shape: record (0, depth) for it."""
+def _plan_rowstream(ops, model, batch_sizes, depth, variant):
+    """What the search does when the row-streaming kernel wins a shape: record (-variant, depth) for it."""
     from mini_sglang_amd import _lib
 
     ws = [model.lm_head] + [w for lw in model.layers for w in (lw.qkv, lw.o, lw.gate_up, lw.down)]
@@ -35,13 +35,14 @@ def _plan_rowstream(ops, model, batch_sizes, depth):
     for M in batch_sizes:
         for w in ws:
             N, K = w.shape
-            if ops.rowstream_supported(M, N, K):
-                ops._SKINNY_PLAN[(w.device.index or 0, M, N, K, K, w.stride(0), _lib.BF16)] = (0, depth)
+            if ops.rowstream_supported(M, N, K, 0, variant):
+                ops._SKINNY_PLAN[(w.device.index or 0, M, N, K, K, w.stride(0), _lib.BF16)] = (-variant, depth)
                 n += 1
     return n
 
 
-def test_small_decode_batches_rowstream_folded_equals_unfolded_and_matches_oracle(dev, monkeypatch):
+@pytest.mark.parametrize("variant", [0, 1], ids=["vector-units", "matrix-cores"])
+def test_small_decode_batches_rowstream_folded_equals_unfolded_and_matches_oracle(dev, monkeypatch, variant):
     from mini_sglang_amd import flashinfer_compat as fi
     from mini_sglang_amd import model as model_mod
     from mini_sglang_amd import ops
@@ -81,7 +82,7 @@ def test_small_decode_batches_rowstream_folded_equals_unfolded_and_matches_oracl
         base, _ = run_all(False)  # library GEMMs (no plans), separate row kernels: the recorded run itself
         for f, lg in zip(rec, base):
             assert torch.equal(lg, f["logits"])
-        planned = _plan_rowstream(ops, eng.model, (1, 2, 3, 4), 16)
+        planned = _plan_rowstream(ops, eng.model, (1, 2, 3, 4), 16, variant)
         assert planned == 4 * (1 + 4 * layers)
         unfolded, unfolded_pool = run_all(False)
         folded, folded_pool = run_all(True)
@@ -96,10 +97,16 @@ def test_small_decode_batches_rowstream_folded_equals_unfolded_and_matches_oracl
         one = dict(decodes[-1], graph=False)
         monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", True)
         eager_folded = replay_forward(eng, one).float().cpu()
-        assert calls == {"norm": 0, "act": 0}, calls
+        # a batch of two: the norms are folded, SiLU.mul (folded at one row only) still is a launch per layer
+        n_act = layers if eng.model.gate_up_ilv else 0  # (fi.silu_and_mul is not counted)
+        assert one["input_ids"].numel() == 2 and calls == {"norm": 0, "act": n_act}, calls
         monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", False)
         eager_unfolded = replay_forward(eng, one).float().cpu()
-        assert calls["norm"] == 2 * layers and calls["act"] + int(not eng.model.gate_up_ilv) * layers == layers, calls
+        assert calls == {"norm": 2 * layers, "act": 2 * n_act}, calls
+        single = next(f for f in reversed(rec) if f["phase"] == "decode" and f["input_ids"].numel() == 1)
+        monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", True)
+        replay_forward(eng, dict(single, graph=False))  # one row: nothing is left outside the projections
+        assert calls == {"norm": 2 * layers, "act": 2 * n_act}, calls
         assert torch.equal(eager_folded, eager_unfolded)
         for i, (f, a, b) in enumerate(zip(rec, unfolded, folded)):
             assert torch.equal(a, b), (i, f["phase"], f["size"])

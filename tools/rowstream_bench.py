@@ -20,7 +20,7 @@ sys.path.insert(0, str(ROOT))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen3-14b")
-    ap.add_argument("--batches", type=int, nargs="*", default=[1, 4])
+    ap.add_argument("--batches", type=int, nargs="*", default=[1, 2, 4, 8])
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--out", default="gpurun_out/rowstream_bench.json")
     args = ap.parse_args()
@@ -42,45 +42,54 @@ def main():
             x = (torch.randn((M, K), device=dev) * 0.5).to(torch.bfloat16)
             out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
             row = dict(name=name, M=M, N=N, K=K, MB=round(N * K * 2 / 1e6, 1))
-            sk = [(sl, nt) for sl, nt in ops.skinny_candidates(M, N, K) if sl]
+            sk = [(sl, nt) for sl, nt in ops.skinny_candidates(M, N, K) if sl > 0]
             ranked = sorted((ops._time_launches_us(lambda w: ops.skinny_linear(x, w, sl, out, nt), ws, 6, 1), sl, nt) for sl, nt in sk)[:3]
             best = min((t(lambda w: ops.skinny_linear(x, w, sl, out, nt), ws), sl, nt) for _, sl, nt in ranked)
             row.update(skinny_us=round(best[0], 2), skinny_plan=best[1:], skinny_tbs=round(N * K * 2 / best[0] / 1e6, 2))
-            if ops.rowstream_supported(M, N, K):
+            best_rs = None
+            for v, tag in ((0, "vec"), (1, "mfma")):
+                if not ops.rowstream_supported(M, N, K, 0, v):
+                    continue
                 for d in (8, 16):
-                    us = t(lambda w: ops.rowstream_linear(x, w, d, out), ws)
-                    row[f"rowstream{d}_us"], row[f"rowstream{d}_tbs"] = round(us, 2), round(N * K * 2 / us / 1e6, 2)
-                d = 16 if row["rowstream16_us"] <= row["rowstream8_us"] else 8
-                if name in ("qkv", "gate_up", "lm_head") and ops.rowstream_supported(M, N, K, ops.ROWSTREAM_ADD_NORM):
+                    us = t(lambda w: ops.rowstream_linear(x, w, d, out, variant=v), ws)
+                    row[f"{tag}{d}_us"], row[f"{tag}{d}_tbs"] = round(us, 2), round(N * K * 2 / us / 1e6, 2)
+                    if best_rs is None or us < best_rs[0]:
+                        best_rs = (us, d, v)
+            if best_rs is not None:
+                _, d, v = best_rs
+                row["rowstream_best"] = dict(us=round(best_rs[0], 2), depth=d, variant=v)
+                if name in ("qkv", "gate_up", "lm_head") and ops.rowstream_supported(M, N, K, ops.ROWSTREAM_ADD_NORM, v):
                     res_in, res_out = (torch.randn((M, K), device=dev).to(torch.bfloat16) for _ in range(2))
                     gamma = torch.ones((K,), dtype=torch.bfloat16, device=dev)
                     xs = x.clone()
 
                     def pair(w):
                         ops.fused_add_rmsnorm(xs, res_in, gamma, 1e-6)
-                        ops.rowstream_linear(xs, w, d, out)
+                        ops.rowstream_linear(xs, w, d, out, variant=v)
 
                     row["norm_then_rowstream_us"] = round(t(pair, ws), 2)
                     row["rowstream_with_norm_us"] = round(t(lambda w: ops.rowstream_linear(x, w, d, out, mode=ops.ROWSTREAM_ADD_NORM, res_in=res_in,
-                                                                                           res_out=res_out, gamma=gamma, eps=1e-6), ws), 2)
-                if name == "down" and ops.rowstream_supported(M, N, K, ops.ROWSTREAM_SILU_INTERLEAVED):
+                                                                                           res_out=res_out, gamma=gamma, eps=1e-6, variant=v), ws), 2)
+                if name == "down" and ops.rowstream_supported(M, N, K, ops.ROWSTREAM_SILU_INTERLEAVED, v):
                     gu = (torch.randn((M, 2 * K), device=dev)).to(torch.bfloat16)
                     act = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
 
                     def pair(w):
                         ops.silu_and_mul_interleaved(gu, act)
-                        ops.rowstream_linear(act, w, d, out)
+                        ops.rowstream_linear(act, w, d, out, variant=v)
 
                     row["act_then_rowstream_us"] = round(t(pair, ws), 2)
-                    row["rowstream_with_act_us"] = round(t(lambda w: ops.rowstream_linear(gu, w, d, out, mode=ops.ROWSTREAM_SILU_INTERLEAVED), ws), 2)
+                    row["rowstream_with_act_us"] = round(t(lambda w: ops.rowstream_linear(gu, w, d, out, mode=ops.ROWSTREAM_SILU_INTERLEAVED,
+                                                                                          variant=v), ws), 2)
             print(json.dumps(row), flush=True)
             res["rows"].append(row)
         del ws
         torch.cuda.empty_cache()
     for M in args.batches:
-        rows = [r for r in res["rows"] if r["M"] == M]
-        layer = lambda key: sum(r.get(key, r["skinny_us"]) for r in rows if r["name"] != "lm_head")  # noqa: E731
-        res[f"layer_us_M{M}"] = dict(skinny=round(layer("skinny_us"), 1), rowstream=round(min(layer("rowstream8_us"), layer("rowstream16_us")), 1))
+        rows = [r for r in res["rows"] if r["M"] == M and r["name"] != "lm_head"]
+        res[f"layer_us_M{M}"] = dict(skinny=round(sum(r["skinny_us"] for r in rows), 1),
+                                     rowstream=round(sum(r.get("rowstream_best", {}).get("us", r["skinny_us"]) for r in rows), 1),
+                                     best=round(sum(min(r["skinny_us"], r.get("rowstream_best", {}).get("us", 1e9)) for r in rows), 1))
     print(json.dumps({k: v for k, v in res.items() if k.startswith("layer_us")}))
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(res, indent=1))
