@@ -68,9 +68,10 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
             r["name"] = name
             if bs <= ops.SKINNY_MAX_M:  # hand-written weight-streaming kernel vs the library's best
                 # flags["fold"]: the row kernel the caller folds into this projection where the row-streaming kernel is planned
-                fold = {"norm": ops.ROWSTREAM_ADD_NORM, "act": ops.ROWSTREAM_SILU, "act_interleaved": ops.ROWSTREAM_SILU_INTERLEAVED}.get(flags.get("fold"))
-                if flags.get("fold", "").startswith("act") and bs > 1:
-                    fold = None  # SiLU.mul is folded at one row only (model.DenseDecoder.forward)
+                kind = flags.get("fold", "")
+                fold = {"norm": ops.ROWSTREAM_ADD_NORM, "act": ops.ROWSTREAM_SILU, "act_interleaved": ops.ROWSTREAM_SILU_INTERLEAVED}.get(kind)
+                if bs > (ops.ROWSTREAM_FOLD_ACT_MAX_M if kind.startswith("act") else ops.ROWSTREAM_FOLD_NORM_MAX_M):
+                    fold = None
                 sk = ops.skinny_tune(x, ws, r["best_us"], fold_mode=fold)
                 r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
                          skinny_used=sk["used"])

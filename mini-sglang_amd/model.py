@@ -338,8 +338,10 @@ class DenseDecoder:
         # kernel in front of it rides in that kernel's staging pass -- fused_add_rmsnorm in front of qkv / gate_up / lm_head
         # (`pending` = the previous projection's output still waiting for its add + norm; the new residual goes to the
         # other one of two buffers, every workgroup is still reading the old one), SiLU.mul in front of down_proj.  Same bits.
+        # Measured inside the captured step (tools/small_batch_ab.py, profiles/r04_small_batch_ab.json): folding the norms is
+        # worth 0.13 / 0.07-0.11 ms per step at one / two rows and nothing at four; SiLU.mul pays at one row only.
         T = x.shape[0]
-        rs_on = _ROWSTREAM_FUSE and self.fused and self.tp_size == 1 and T <= ops.ROWSTREAM_MAX_M
+        rs_on = _ROWSTREAM_FUSE and self.fused and self.tp_size == 1 and T <= ops.ROWSTREAM_FOLD_NORM_MAX_M
         pending: Optional[torch.Tensor] = None
         spare: Optional[torch.Tensor] = None
 
@@ -388,8 +390,8 @@ class DenseDecoder:
             nxt = self.final_norm if last else self.layers[li + 1].input_norm
             d_gu = ops.rowstream_planned(T, lw.gate_up, ops.ROWSTREAM_ADD_NORM) if rs_on else None
             act_mode = ops.ROWSTREAM_SILU_INTERLEAVED if self.gate_up_ilv else ops.ROWSTREAM_SILU
-            # SiLU.mul in the staging pass pays at one row only (M = 4: 45 vs 41 us for the pair, profiles/r04_rowstream_bench.json)
-            d_dn = ops.rowstream_planned(T, lw.down, act_mode) if rs_on and T == 1 else None
+            # SiLU.mul in the staging pass pays at one row only (M = 4: 43 vs 39 us for the pair, profiles/r04_rowstream_bench.json)
+            d_dn = ops.rowstream_planned(T, lw.down, act_mode) if rs_on and T <= ops.ROWSTREAM_FOLD_ACT_MAX_M else None
             if d_gu:  # o_proj, then post-attention add + norm inside the gate_up launch
                 gu = norm_into(lw.gate_up, ops.linear(o.view(-1, self.q_dim), lw.o), lw.post_norm, d_gu)
             else:

@@ -634,6 +634,7 @@ def skinny_candidates(M: int, N: int, K: int):
 # 0.8-0.9 us per fold; the search below works on back-to-back times, which also have rowstream qkv 0.7 us behind the
 # matrix-core kernel where the step has it ahead)
 ROWSTREAM_FOLD_BONUS_US = 1.5
+ROWSTREAM_FOLD_NORM_MAX_M, ROWSTREAM_FOLD_ACT_MAX_M = 2, 1  # rows up to which the decoder layer folds (model.DenseDecoder.forward)
 
 
 def skinny_tune(x: torch.Tensor, weights, library_us: float, iters: int = 8, fold_mode: Optional[int] = None) -> dict:

@@ -1,6 +1,7 @@
 """The smallest decode batches (1 .. 4 sequences) of a Qwen3-14B-dimension decoder with every projection on the
 row-streaming kernel (csrc/gemm_rowstream.hip) and the layer's row kernels folded into its staging pass
-(model.DenseDecoder.forward: fused_add_rmsnorm in front of qkv / gate_up / lm_head, SiLU.mul in front of down_proj):
+(model.DenseDecoder.forward: at one or two rows fused_add_rmsnorm in front of qkv / gate_up / lm_head, at one row SiLU.mul in
+front of down_proj):
 
   * the folded forward equals the unfolded one BIT FOR BIT (logits and KV pool), eager and under graph replay;
   * both are the reference's composition (P/models/qwen3.py:18-81) within the bf16 band of tests/test_gpu_model_14b.py
