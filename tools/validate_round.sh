@@ -55,6 +55,10 @@ PY
 )
 for cfg in "qwen3-14b 2" "qwen3-14b 4" "qwen3-14b 8" "qwen3-32b 4" "llama-3.1-70b 8"; do set -- $cfg; timeout 200 python bench.py --model $1 --rank-shard $2 --tp1-ms $MS --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${TAG}_rank_shard_$1_tp$2.json; cut -c1-200 gpurun_out/${TAG}_rank_shard_$1_tp$2.json; done
 bash tools/trace_small_batch.sh ${TAG} 1 > gpurun_out/${TAG}_b1_trace.log 2>&1; head -3 gpurun_out/${TAG}_b1_kernel_breakdown.txt
+# batches <= 8: the row-streaming projection against the 16-row kernel back to back, and inside the captured step with / without the folds
+hipcc -O3 --offload-arch=gfx950 tools/persist_probe.hip -o tools/build/persist_probe 2>/dev/null; timeout 100 tools/build/persist_probe > gpurun_out/${TAG}_persist_probe.txt 2>&1; head -8 gpurun_out/${TAG}_persist_probe.txt
+timeout 300 python tools/rowstream_bench.py --iters 8 --out gpurun_out/${TAG}_rowstream_bench.json 2>/dev/null | tail -1 | cut -c1-400
+timeout 400 python tools/small_batch_ab.py --out gpurun_out/${TAG}_small_batch_ab.json 2>/dev/null | grep -v gemm_tune | head -5
 # same-box A/B of the decode attention kernels, per-wave clock stamps of the default one, MFMA counters of prefill attention
 cd $R
 timeout 300 python tools/decode_ab.py --shape 14b,14b_tp4,32b_tp4,70b_tp8,0.6b,14b_b32 --impls 1,94,0,22,23,32,72,92 --out gpurun_out/${TAG}_decode_ab.json 2>&1 | grep impl > gpurun_out/${TAG}_decode_ab.txt
