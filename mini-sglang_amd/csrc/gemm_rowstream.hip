@@ -22,7 +22,12 @@
 //   3      x is the previous projection's output: stages fused_add_rmsnorm(x, residual) (every workgroup computes the
 //          row statistics itself, in the order of rmsnorm_wide_row_kernel: same bits), workgroup 0 writes the new
 //          residual to `res_out` (a different buffer: the other workgroups are still reading `res_in`).
-// M is padded to 1 / 2 / 4 / 8 staged rows (zeros).  K must be a multiple of 512.
+// M is padded to 1 / 2 / 4 / 8 staged rows (zeros).  This first form (variant 0, K % 512 == 0) is the fastest at M = 1;
+// from two rows on its M LDS reads and 4 M quarter-rate v_dot2 per load are the limit (gate_up 60 -> 70 -> 106 -> 178 us at
+// M = 1 / 2 / 4 / 8) and the matrix-core form further down (variant 1: v_mfma_f32_4x4x4_16b, units of four rows x 128 k)
+// takes over.  Measured on Qwen3-14B (profiles/r04_rowstream_bench.json, r04_small_batch_ab.json): gate_up 64 -> 57 us
+// (6.2 TB/s), down_proj 44 -> 31, lm_head 251 -> 234 (6.66 TB/s) at M = 1, the same within 4 us up to M = 8; the captured
+// decode step 6.65 -> 5.79 ms at B = 1, 6.85 -> 6.23 at 2, 7.17 -> 6.67 at 4, 7.69 -> 7.42 at 8.
 #include <type_traits>
 
 #include "common.h"
@@ -459,7 +464,7 @@ extern "C" int msgl_rowstream_gemm_nt(void* out, const void* x, const void* w, i
   }
   MSGL_REQUIRE(depth == 8 || depth == 16, "rowstream_gemm_nt: depth %d (8 or 16 units in flight per wave)", depth);
   const int64_t x_cols = mode == kRsSiluHalves || mode == kRsSiluIlv ? 2ll * K : K;
-  MSGL_REQUIRE(ldx >= x_cols && ldw >= K && ldo >= N && ldx % 8 == 0 && ldw % 8 == 0,
+  MSGL_REQUIRE(ldx >= x_cols && ldw >= K && ldw < (1ll << 28) && ldo >= N && ldx % 8 == 0 && ldw % 8 == 0,
                "rowstream_gemm_nt: leading dimensions (%lld, %lld, %lld)", (long long)ldx, (long long)ldw, (long long)ldo);
   MSGL_REQUIRE(aligned16(x) && aligned16(w) && (reinterpret_cast<uintptr_t>(out) & 1u) == 0,
                "rowstream_gemm_nt: x and w must be 16-byte aligned");
