@@ -40,6 +40,22 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 METRIC = "decode tokens/s/GPU + p50 TTFT, Qwen3-14B TP=1 and Qwen3-32B TP=4"
 
 
+def product_code_fingerprint() -> str:
+    """sha256 over the product's sources (kernels, host C++, package Python, the C header): a number recorded under profiles/
+    by another process (the reference-driven step time) carries the fingerprint of the code that produced it, and this file
+    marks it stale when HEAD's sources differ."""
+    import hashlib
+
+    h = hashlib.sha256()
+    pkg = ROOT / "mini-sglang_amd"
+    files = sorted(list((pkg / "csrc").glob("*")) + list(pkg.glob("*.py")) + list((ROOT / "include").glob("*.h")))
+    for f in files:
+        if f.is_file():
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def bench_contexts(num_seqs: int, seed: int = 0):
     """(request, decode step) pairs drawn uniformly from all decoded tokens of the reference's
     offline benchmark => context lengths with its token-weighted mean (902.8 at 256 seqs)."""
@@ -457,6 +473,7 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
                             weight_TBps=round(2.0 * r["N"] * r["K"] / r["best_us"] / 1e6, 2),
                             **({"hand_written": r["kernel"], "library_best_us": round(r["library_best_us"], 1)}
                                if r.get("skinny_used") else {}),
+                            **({"fold_credit_us": r["fold_credit_us"]} if r.get("fold_credit_us") else {}),
                             **({"projection_then_silu_us": round(r["silu_unfused_us"], 1),
                                 "fused_silu_epilogue_us": round(r["silu_fused_us"], 1), "fused_silu_used": r["silu_fused_used"]}
                                if r.get("silu_fused_us") else {})) for r in engine.gemm_report],
@@ -561,9 +578,14 @@ def main() -> None:
             d = json.loads(ref_runs[-1].read_text())
             # "committed": recorded by the GPU test suite on a box of the same kind and kept under profiles/; this file may
             # not import oracle/_ref (the reference), so it cannot re-measure it
+            # stale = the sources have changed since that run was recorded (fingerprint stored by the test that wrote the file;
+            # files from before round 5 carry none): the number then describes an EARLIER state of the kernels
+            fp = product_code_fingerprint()
             result["reference_driven"] = {"kind": "committed", "decode_ms_per_step": d["decode_ms_per_step_median"], "tokens_per_s": d["tokens_per_s"],
                                           "vs_this_run_ms_per_step": d["decode_ms_per_step_median"] / ms_per_step,
-                                          "driver": d["driver"], "source": f"profiles/{ref_runs[-1].name}"}
+                                          "driver": d["driver"], "source": f"profiles/{ref_runs[-1].name}",
+                                          "recorded_on_code": d.get("code_fingerprint"), "this_code": fp,
+                                          "stale": d.get("code_fingerprint") != fp}
         except Exception as e:
             result["reference_driven"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_e2e:
@@ -586,6 +608,19 @@ def main() -> None:
         except Exception as e:  # never lose the GPU numbers to a host-side problem
             result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
+        # the LAST object of the line (a reader that keeps only the tail of stdout still sees the headline numbers)
+        e2e = result.get("e2e_offline", {})
+        result["summary"] = {
+            "ms_per_step": round(ms_per_step, 3), "tokens_per_s": round(result["value"]),
+            "step_frac_of_8TBps": round(result["step_roofline"]["frac"], 4),
+            "attn_decode_us": round(result["roofline"]["us_per_launch"], 1), "attn_decode_frac": round(result["roofline"]["frac"], 4),
+            "small_batch_ms_per_step": result.get("small_batch_ms_per_step"),
+            "ttft_p50_ms": result.get("ttft_p50_ms"),
+            "e2e_offline_tok_s": {k: round(v["throughput_tok_s"]) for k, v in e2e.items() if "throughput_tok_s" in v},
+            "prefill_attn_frac": (result.get("prefill_roofline") or {}).get("frac"),
+            "reference_driven_ms": (result.get("reference_driven") or {}).get("decode_ms_per_step"),
+            "reference_driven_stale": (result.get("reference_driven") or {}).get("stale"),
+        }
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -61,10 +61,10 @@ enum { kP2PKindOneShot = 1, kP2PKindTwoShot = 2, kP2PKindFusedNorm = 3, kP2PKind
 
 __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int world, int phase, bool release,
                                             uint32_t spin_limit, bool bad, int kind) {
-  __shared__ int s_bad;
+  __shared__ int s_bad, s_gave_up;
   P2PHeader* self = reinterpret_cast<P2PHeader*>(peers.base[rank]);
   const int b = blockIdx.x;
-  if (threadIdx.x == 0) s_bad = bad ? 1 : 0;
+  if (threadIdx.x == 0) { s_bad = bad ? 1 : 0; s_gave_up = 0; }
   __syncthreads();  // everything this block did before the barrier is issued
   if (release) __threadfence_system();
   uint32_t seq = 0;
@@ -86,23 +86,31 @@ __device__ __forceinline__ bool p2p_barrier(const P2PPeers& peers, int rank, int
         break;
       }
       if (spins > spin_limit) {
-        __hip_atomic_store(&self->error,
-                           (1u + (uint32_t)phase) | ((uint32_t)kind << 4) | (((uint32_t)b & 255u) << 8) | (threadIdx.x << 16),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // first verdict sticks (a peer's told word may have landed meanwhile: it names the root cause, keep it)
+        uint32_t expect = 0;
+        __hip_atomic_compare_exchange_strong(
+            &self->error, &expect,
+            (1u + (uint32_t)phase) | ((uint32_t)kind << 4) | (((uint32_t)b & 255u) << 8) | (threadIdx.x << 16),
+            __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         s_bad = 1;
+        s_gave_up = 1;
         break;
       }
     }
   }
   __syncthreads();
   const bool out = s_bad != 0;
-  if (out && !bad && threadIdx.x < world && (int)threadIdx.x != rank) {
-    // first block of this rank to see the failure: tell every peer (sticky there as here; their kernels poison from
-    // their next barrier / next launch on, and their hosts raise at the next poll)
+  if (s_gave_up != 0 && threadIdx.x < world && (int)threadIdx.x != rank) {
+    // only a rank whose OWN wait ran out tells its peers (a rank that left its spin because a peer's word arrived would
+    // otherwise overwrite the root cause at world >= 3), and it writes by compare-and-swap from 0 so that the first
+    // verdict in a header sticks.  Sticky there as here: the peers' kernels poison from their next barrier / next launch
+    // on, and their hosts raise at the next poll.
     P2PHeader* peer = reinterpret_cast<P2PHeader*>(peers.base[threadIdx.x]);
-    __hip_atomic_store(&peer->error,
-                       (1u + (uint32_t)phase) | ((uint32_t)kind << 4) | (((uint32_t)b & 255u) << 8) | ((uint32_t)rank << 16) | (1u << 20),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t expect = 0;
+    __hip_atomic_compare_exchange_strong(
+        &peer->error, &expect,
+        (1u + (uint32_t)phase) | ((uint32_t)kind << 4) | (((uint32_t)b & 255u) << 8) | ((uint32_t)rank << 16) | (1u << 20),
+        __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0) self->seq[b][phase] = seq;
   return out;

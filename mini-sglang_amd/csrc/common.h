@@ -34,6 +34,22 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 int device_cu_count();  // cached, host.cpp
 
+// A kernel that needs more than 64 KB of dynamic LDS has to ask for it with hipFuncSetAttribute, and the attribute belongs
+// to the function object of the CURRENT device: one flag per (call site, device), safe under concurrent callers.
+struct PerDeviceOnce {
+  unsigned done = 0;  // bit d = the attribute is set on device d (devices above 31 ask every time)
+  template <typename F>
+  bool ensure(F&& set_attribute) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned bit = dev >= 0 && dev < 32 ? 1u << dev : 0u;
+    if (bit && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) return true;
+    if (!set_attribute()) return false;
+    if (bit) __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+    return true;
+  }
+};
+
 // ---- 16-bit float element traits ---------------------------------------------
 struct BF16 {};  // storage: uint16_t, upper half of an fp32
 struct FP16 {};  // storage: IEEE half

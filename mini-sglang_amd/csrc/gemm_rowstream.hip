@@ -396,14 +396,13 @@ __global__ __launch_bounds__(kRsThreads, 2) void rowstream4_gemm_kernel(const Ro
 template <typename T, int MM, int D, int MODE, int V>
 static int launch_rowstream_t(const RowStreamParams& p, int G, size_t lds, hipStream_t s) {
   auto* kernel = V ? &rowstream4_gemm_kernel<T, MM, D, MODE> : &rowstream_gemm_kernel<T, MM, D, MODE>;
-  static bool attr_done = false;  // per instantiation: more than 64 KB of dynamic LDS has to be requested
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kRsLdsBudget) !=
-        hipSuccess) {
-      set_error("rowstream_gemm_nt: cannot reserve %d bytes of LDS: %s", kRsLdsBudget, hipGetErrorString(hipGetLastError()));
-      return MSGL_ELAUNCH;
-    }
-    attr_done = true;
+  static PerDeviceOnce lds_attr;  // per instantiation and device: more than 64 KB of dynamic LDS has to be requested
+  if (!lds_attr.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kRsLdsBudget) == hipSuccess;
+      })) {
+    set_error("rowstream_gemm_nt: cannot reserve %d bytes of LDS: %s", kRsLdsBudget, hipGetErrorString(hipGetLastError()));
+    return MSGL_ELAUNCH;
   }
   kernel<<<dim3((unsigned)G), dim3(kRsThreads), lds, s>>>(p);
   return MSGL_OK;

@@ -204,16 +204,15 @@ static int launch_wstream_t(uint16_t* out, float* part, const uint16_t* x, const
   const dim3 grid((unsigned)(N / (16 * NT * kWsWaves)), (unsigned)k_splits), block(64 * kWsWaves);
   const size_t lds = 2u * 16 * MT * kWsPitch;
   const int nsteps = K / kWsStepK;
-  static bool attr_done = false;  // per instantiation: more than 64 KB of dynamic LDS has to be requested
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_kernel<T, MT, NT, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_kernel<T, MT, NT, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      set_error("wstream_gemm_nt: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
-      return MSGL_ELAUNCH;
-    }
-    attr_done = true;
+  static PerDeviceOnce lds_attr;  // per instantiation and device: more than 64 KB of dynamic LDS has to be requested
+  if (!lds_attr.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_kernel<T, MT, NT, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_kernel<T, MT, NT, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      })) {
+    set_error("wstream_gemm_nt: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
+    return MSGL_ELAUNCH;
   }
   if (k_splits == 1) {
     wstream_gemm_kernel<T, MT, NT, false><<<grid, block, lds, s>>>(out, nullptr, x, w, M, N, nsteps, ldx, ldw, ldo);

@@ -13,6 +13,7 @@ import gc
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, NamedTuple, Optional
 
+import numpy as np
 import torch
 
 from . import flashinfer_compat as fi
@@ -24,52 +25,78 @@ from .model import Communicator, DenseDecoder, ModelConfig
 
 
 # ------------------------------------------------------------------------------ sampler
-@dataclass
-class BatchSamplingArgs:
+_T_FLOOR = 1e-6  # the reference sampler's lower clamp on temperature and on top_p (P/engine/sample.py:58)
+
+
+class SamplingPlan(NamedTuple):
+    """What one batch's token draw needs on the device.  `temperatures is None` = every row is an argmax.  The field
+    names are the ones P/engine/sample.py:13-17 gives its argument record (tests and the plugin read them)."""
     temperatures: Optional[torch.Tensor]
     top_k: Optional[torch.Tensor] = None
     top_p: Optional[torch.Tensor] = None
 
 
-def _device_tensor(data: List, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
-    return torch.tensor(data, dtype=dtype, pin_memory=True).to(device, non_blocking=True)
+def plan_sampling_host(temperature: "np.ndarray", top_k: "np.ndarray", top_p: "np.ndarray", vocab_size: int):
+    """The clamps of P/engine/sample.py:53-68 over whole columns (numpy; no per-request Python arithmetic).
+
+    Input: one entry per request of SamplingParams.{temperature, top_k, top_p}.  Output: None when the whole batch is
+    greedy, else an (f32 temperatures, i32 top_k | None, f32 top_p | None) triple.  A greedy row inside a sampled batch gets
+    the floor temperature (its softmax is then a one-hot up to ties); top_k < 1 means 'no limit' = the vocabulary size;
+    top_p is clamped into [floor, 1].  A filter column that filters nothing for any row is dropped, so the cheaper
+    draw kernel is chosen."""
+    greedy = ((temperature <= 0.0) | (top_k == 1)) & (top_p == 1.0)  # SamplingParams.is_greedy, P/core.py:23-25
+    if bool(greedy.all()):
+        return None
+    t = np.maximum(np.where(greedy, 0.0, temperature), _T_FLOOR).astype(np.float32)
+    k = np.where(top_k >= 1, top_k, vocab_size).astype(np.int32)
+    p = np.clip(top_p, _T_FLOOR, 1.0).astype(np.float32)
+    return t, (k if bool((k != vocab_size).any()) else None), (p if bool((top_p < 1.0).any()) else None)
 
 
-@dataclass
 class Sampler:
-    """P/engine/sample.py:49-75 with the same clamps (MIN_T = MIN_P = 1e-6)."""
-    device: torch.device
-    vocab_size: int
+    """Batch sampler behind the interface of P/engine/sample.py:49-75 (`prepare` on the host, `sample` enqueues).
 
-    def prepare(self, batch: Batch) -> BatchSamplingArgs:
-        params = [r.sampling_params for r in batch.reqs]
-        if all(p.is_greedy for p in params):
-            return BatchSamplingArgs(temperatures=None)
-        MIN_P = MIN_T = 1e-6
-        ts = [max(0.0 if p.is_greedy else p.temperature, MIN_T) for p in params]
-        top_ks = [p.top_k if p.top_k >= 1 else self.vocab_size for p in params]
-        top_ps = [min(max(p.top_p, MIN_P), 1.0) for p in params]
-        temperatures = _device_tensor(ts, torch.float32, self.device)
-        top_k = top_p = None
-        if any(k != self.vocab_size for k in top_ks):
-            top_k = _device_tensor(top_ks, torch.int32, self.device)
-        if any(p < 1.0 for p in top_ps):
-            top_p = _device_tensor(top_ps, torch.float32, self.device)
-        return BatchSamplingArgs(temperatures, top_k=top_k, top_p=top_p)
+    prepare: the requests' three sampling scalars are gathered into columns once, clamped by `plan_sampling_host`, packed
+    into ONE pinned staging row and sent with ONE asynchronous copy; the device tensors are views of that upload
+    (top_k reinterpreted as int32)."""
 
-    def sample(self, logits: torch.Tensor, args: BatchSamplingArgs) -> torch.Tensor:
+    def __init__(self, device: torch.device, vocab_size: int) -> None:
+        self.device, self.vocab_size = device, vocab_size
+        self._pin = device.type == "cuda"
+
+    def prepare(self, batch: Batch) -> SamplingPlan:
+        n = len(batch.reqs)
+        cols = np.fromiter((v for r in batch.reqs for v in
+                            (r.sampling_params.temperature, r.sampling_params.top_k, r.sampling_params.top_p)),
+                           dtype=np.float64, count=3 * n).reshape(n, 3)
+        plan = plan_sampling_host(cols[:, 0], cols[:, 1].astype(np.int64), cols[:, 2], self.vocab_size)
+        if plan is None:
+            return SamplingPlan(None)
+        live = [c for c in plan if c is not None]
+        host = torch.empty((len(live), n), dtype=torch.float32, pin_memory=self._pin)
+        for row, c in zip(host.numpy(), live):
+            row.view(c.dtype)[:] = c  # int32 top_k travels as raw bits in the f32 staging row
+        dev = iter(host.to(self.device, non_blocking=True).unbind(0))
+        t, k, p = plan
+        return SamplingPlan(next(dev), None if k is None else next(dev).view(torch.int32),
+                            None if p is None else next(dev))
+
+    def sample(self, logits: torch.Tensor, args: SamplingPlan) -> torch.Tensor:
         if args.temperatures is None:  # greedy: first index of the row max
             return ops.argmax_rows(logits)
-        # same call sequence as sample_impl (sample.py:24-45); `softmax` is deferred, so a temperature-only batch
+        # same op sequence as sample_impl (sample.py:24-45); `softmax` is deferred, so a temperature-only batch
         # is one fused draw from the logits and only the top-k / top-p variants materialise probabilities
         probs = fi.sampling.softmax(logits, args.temperatures)
-        if args.top_k is None and args.top_p is None:
-            return fi.sampling.sampling_from_probs(probs)
-        if args.top_p is None:
-            return fi.sampling.top_k_sampling_from_probs(probs, args.top_k)
-        if args.top_k is None:
-            return fi.sampling.top_p_sampling_from_probs(probs, args.top_p)
-        return fi.sampling.top_k_top_p_sampling_from_probs(probs, args.top_k, args.top_p)
+        draw = {
+            (False, False): lambda: fi.sampling.sampling_from_probs(probs),
+            (True, False): lambda: fi.sampling.top_k_sampling_from_probs(probs, args.top_k),
+            (False, True): lambda: fi.sampling.top_p_sampling_from_probs(probs, args.top_p),
+            (True, True): lambda: fi.sampling.top_k_top_p_sampling_from_probs(probs, args.top_k, args.top_p),
+        }
+        return draw[(args.top_k is not None, args.top_p is not None)]()
+
+
+BatchSamplingArgs = SamplingPlan  # the reference's name for the record
 
 
 # ------------------------------------------------------------------------------ config

@@ -74,7 +74,7 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     fold = None
                 sk = ops.skinny_tune(x, ws, r["best_us"], fold_mode=fold)
                 r.update(skinny_us=sk["skinny_us"], skinny_slices=sk["slices"], skinny_row_tiles=sk["row_tiles"],
-                         skinny_used=sk["used"])
+                         skinny_used=sk["used"], fold_credit_us=sk.get("fold_credit_us", 0.0))
                 if sk["used"]:
                     r["library_best_us"], r["best_us"] = r["best_us"], sk["skinny_us"]
                     r["kernel"] = (f"msgl::rowstream{'4' if sk['slices'] else ''}_gemm_kernel[{sk['row_tiles']} loads in flight per lane]" if sk["slices"] <= 0 else

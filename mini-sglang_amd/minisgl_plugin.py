@@ -20,6 +20,8 @@ All three are class / module attribute assignments made at install time; no refe
 """
 from __future__ import annotations
 
+import weakref
+
 import importlib
 import os
 import sys
@@ -253,11 +255,11 @@ def _install_fused_gated_mlp() -> None:
         # the weight rows ARE permuted: the reference forward (contiguous [gate | up] halves) would be silently wrong on
         # them, so every input either takes the interleaved path or is refused
         w = self.gate_up_proj.weight
-        if w.data_ptr() != getattr(self, "_msgl_gate_up_ptr", None):
+        if not _holds_permuted_rows(self, w):
             # load_state_dict (P/layers/base.py:31-49) REPLACES the tensor: the new one holds the reference's [gate; up]
             # rows, the permuted storage is gone -- this layer is a plain reference layer again until the next capture
             # converts it (an IN-PLACE rewrite cannot be seen from here: restore_gate_up_layout() first, see its docstring)
-            self._msgl_gate_up_ilv, self._msgl_gate_up_ptr = False, None
+            self._msgl_gate_up_ilv, self._msgl_gate_up_ptr, self._msgl_gate_up_ref = False, None, None
             return reference_forward(self, x)
         if not x.is_cuda:
             raise RuntimeError("GatedMLP with interleaved gate_up rows runs on the HIP device only (no CPU fallback)")
@@ -272,6 +274,15 @@ def _install_fused_gated_mlp() -> None:
     forward._msgl_reference = reference_forward  # type: ignore[attr-defined]
     GatedMLP.forward = forward
     _STATE["fused_gated_mlp"] = True
+
+
+def _holds_permuted_rows(op: Any, w: Any) -> bool:
+    """True when `w` (the layer's current gate_up weight) is the very tensor `_interleave_gated_mlps` permuted.  The
+    address alone is not enough: after load_state_dict replaces the tensor the caching allocator may hand the NEW tensor the
+    freed block at the same address, so the mark is (address, a weak reference to the tensor object): a replaced tensor is a
+    different object (or the weak reference is dead) whatever its address."""
+    ref = getattr(op, "_msgl_gate_up_ref", None)
+    return ref is not None and ref() is w and w.data_ptr() == getattr(op, "_msgl_gate_up_ptr", None)
 
 
 def _interleave_gated_mlps(model: Any) -> int:
@@ -302,6 +313,7 @@ def _interleave_gated_mlps(model: Any) -> int:
                 w.copy_(ops.interleave_gate_up(w))
                 op._msgl_gate_up_ilv = True
                 op._msgl_gate_up_ptr = gu.weight.data_ptr()  # the storage that holds permuted rows (checked per forward)
+                op._msgl_gate_up_ref = weakref.ref(gu.weight)  # ... and the tensor object itself (_holds_permuted_rows)
                 done += 1
             return
         if isinstance(op, BaseOP):
@@ -342,10 +354,10 @@ def restore_gate_up_layout(model: Any) -> int:
         nonlocal done
         if getattr(op, "_msgl_gate_up_ilv", False):
             w = op.gate_up_proj.weight
-            if w.data_ptr() == getattr(op, "_msgl_gate_up_ptr", None):  # else: already replaced by un-permuted rows
+            if _holds_permuted_rows(op, w):  # else: already replaced by un-permuted rows
                 (w.data if hasattr(w, "data") else w).copy_(gate_up_reference(op))
             op._msgl_gate_up_ilv = False
-            op._msgl_gate_up_ptr = None
+            op._msgl_gate_up_ptr = op._msgl_gate_up_ref = None
             done += 1
             return
         if isinstance(op, BaseOP):

@@ -41,6 +41,28 @@ def test_sampler_prepare_matches_reference(golden_dir):
                 assert torch.equal(torch.tensor(mine, dtype=dt), ref), name
 
 
+def test_product_sampler_prepare_matches_reference(golden_dir):
+    """The product's Sampler.prepare (column-wise numpy clamps, one packed upload) against the outputs of the reference's
+    Sampler.prepare stored by tests/golden/make_golden.py (P/engine/sample.py:53-68): same tensors, same dtypes, a filter
+    column present exactly when the reference builds one."""
+    from types import SimpleNamespace
+
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.engine import Sampler
+
+    gold = torch.load(golden_dir / "sampler_prepare.pt")
+    sampler = Sampler(torch.device("cpu"), gold["vocab"])
+    for name, c in gold["sets"].items():
+        reqs = [SimpleNamespace(sampling_params=SamplingParams(temperature=t, top_k=k, top_p=p)) for t, k, p in c["params"]]
+        plan = sampler.prepare(SimpleNamespace(reqs=reqs))
+        for mine, ref, dt in ((plan.temperatures, c["temperatures"], torch.float32), (plan.top_k, c["top_k"], torch.int32),
+                              (plan.top_p, c["top_p"], torch.float32)):
+            if ref is None:
+                assert mine is None, name
+            else:
+                assert mine is not None and mine.dtype == dt and torch.equal(mine, ref), name
+
+
 def test_product_sampling_params_is_greedy_matches_reference(golden_dir):
     from mini_sglang_amd.core import SamplingParams
 

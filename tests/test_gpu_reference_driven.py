@@ -407,7 +407,7 @@ def test_reference_driven_qwen3_14b_decode_step_is_the_benchmarked_path(dev):
     free, total = torch.cuda.mem_get_info()
     if total < 200 * (1 << 30):
         pytest.skip("needs a 288 GB part")
-    from bench import bench_contexts
+    from bench import bench_contexts, product_code_fingerprint
 
     B, steps = 256, 45
     contexts = bench_contexts(B)
@@ -433,7 +433,8 @@ def test_reference_driven_qwen3_14b_decode_step_is_the_benchmarked_path(dev):
                   gemm=[dict(name=r["name"], M=r["M"], N=r["N"], K=r["K"], us=round(r["best_us"], 1),
                              kernel=r["kernel"][:80]) for r in rec["gemm_report"]],
                   refined_in_graph=[dict(name=r["name"], chosen=r["chosen"], changed=r["changed"]) for r in rec.get("refine_report", [])],
-                  driver="reference LLM/Scheduler/GraphRunner via minisgl_plugin.install()", device=rec["device"])
+                  driver="reference LLM/Scheduler/GraphRunner via minisgl_plugin.install()", device=rec["device"],
+                  code_fingerprint=product_code_fingerprint())
     print(f"\n[refdrive 14B] decode {med:.2f} ms/step ({B * 1e3 / med:.0f} tok/s) over {len(ms)} steps "
           f"[{ms[0]:.2f}..{ms[-1]:.2f}], prefill {len(pre)} chunks")
     dump("refdrive_14b.json", report)

@@ -137,3 +137,59 @@ def test_small_decode_batches_rowstream_folded_equals_unfolded_and_matches_oracl
     finally:
         eng.shutdown()
         ops.reset_gemm_plans()
+
+
+@pytest.mark.parametrize("kind", ["qkv", "gate_up", "down", "lm_head", "qkv+down", "gate_up+lm_head"])
+def test_rowstream_folds_with_mixed_plans_equal_unfolded(dev, monkeypatch, kind):
+    """The search plans the row-streaming kernel per SHAPE, so a layer usually has it for some projections only: every
+    mixed state of model.DenseDecoder.forward's fold logic (only qkv, only gate_up, only down_proj -- SiLU.mul folded but
+    the add + norm left to its own launch -- only the LM head, and two pairs) must equal the unfolded forward bit for bit,
+    logits and KV pool, eager decode at one and two rows."""
+    from mini_sglang_amd import _lib
+    from mini_sglang_amd import model as model_mod
+    from mini_sglang_amd import ops
+    from mini_sglang_amd.core import SamplingParams
+    from mini_sglang_amd.engine import Engine, EngineConfig
+    from mini_sglang_amd.offline import OfflineRunner
+    from replay_util import record_offline_runner, replay_forward
+
+    layers = 2
+    m = _cfg(layers)
+    cfg = EngineConfig(model=m, dtype=torch.bfloat16, max_running_req=2, page_size=16, cuda_graph_bs=[],
+                       max_seq_len_override=256, num_page_override=64, seed=11, gemm_tune="off")
+    eng = Engine(cfg, dev)
+    try:
+        rnd = random.Random(5)
+        rec = []
+        runner = OfflineRunner(eng, max_extend_tokens=64, seed=1)
+        record_offline_runner(runner, eng, rec)
+        for n_req in (1, 2):
+            prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(2, 9))] for _ in range(n_req)]
+            runner.generate(prompts, [SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True) for _ in prompts])
+        assert {f["size"] for f in rec if f["phase"] == "decode"} == {1, 2}
+        chosen = kind.split("+")
+        mdl = eng.model
+        group = {"qkv": [lw.qkv for lw in mdl.layers], "gate_up": [lw.gate_up for lw in mdl.layers],
+                 "down": [lw.down for lw in mdl.layers], "lm_head": [mdl.lm_head]}
+        for M in (1, 2):
+            for k in chosen:
+                for w in group[k]:
+                    N, K = w.shape
+                    assert ops.rowstream_supported(M, N, K, 0, 1)
+                    ops._SKINNY_PLAN[(w.device.index or 0, M, N, K, K, w.stride(0), _lib.BF16)] = (-1, 16)
+
+        def run_all(fold: bool):
+            monkeypatch.setattr(model_mod, "_ROWSTREAM_FUSE", fold)
+            eng.kv_cache.pool.zero_()
+            out = [replay_forward(eng, dict(f, graph=False)).float().cpu() for f in rec]
+            torch.cuda.synchronize()
+            return out, eng.kv_cache.pool.clone()
+
+        unfolded, pool_u = run_all(False)
+        folded, pool_f = run_all(True)
+        for i, (f, a, b) in enumerate(zip(rec, unfolded, folded)):
+            assert torch.isfinite(a).all() and torch.equal(a, b), (kind, i, f["phase"], f["size"])
+        assert torch.equal(pool_u, pool_f)
+    finally:
+        eng.shutdown()
+        ops.reset_gemm_plans()

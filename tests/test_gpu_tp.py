@@ -55,9 +55,11 @@ def launch(mode: str, world: int, timeout: float = 240.0):
     return [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_p2p_collectives_known_answers(dev, world):
-    res = launch("collectives", world)
+    """World 8 = the width of the flag arrays (kP2PMaxRanks in csrc/comm_p2p.hip) and BASELINE config 5 (70B TP8): eight
+    rank processes on the one GPU of the box, the reference's known answers of tests/kernel/test_comm.py:96-149."""
+    res = launch("collectives", world, timeout=240.0 if world <= 4 else 600.0)
     for r in res:
         assert r["error"] == 0, "a flag barrier timed out"
         assert r["fused_allreduce_norm_shapes"] >= 4, "the fused all-reduce + add + RMSNorm kernel was not exercised"
@@ -86,6 +88,18 @@ def test_p2p_barrier_timeout_poisons_and_raises(dev):
     # the first collective spun until the limit, the later ones saw the sticky word and returned at once
     assert r0["one_shot_seconds"] < max(0.05, 0.2 * r0["two_shot_seconds"]), r0
     print(f"\n[p2p timeout] gave up after {r0['two_shot_seconds']:.2f} s (limit 100k polls); next collective {r0['one_shot_seconds'] * 1e3:.1f} ms")
+
+
+def test_p2p_timeout_root_cause_survives_at_world_3(dev):
+    """only the rank whose own wait ran out tells its peers, and the first verdict in a header sticks -- the
+    failing rank's diagnosis (phase, block, the peer it waited for) is not overwritten by a live peer that merely heard of it."""
+    r0, r1, r2 = launch("root_cause", 3, timeout=240.0)
+    assert r0["all_nan"] and r1["all_nan"]
+    w0, w1, w2 = r0["error_word"], r1["error_word"], r2["error_word"]
+    assert w0 != 0 and not w0 & (1 << 20) and (w0 >> 16) & 15 == 2, hex(w0)   # rank 0 waited for rank 2: its own word
+    for w in (w1, w2):
+        assert w & (1 << 20) and (w >> 16) & 15 == 0 and (w & 0xff) == (w0 & 0xff), (hex(w), hex(w0))
+    assert r1["seconds"] < 60.0   # rank 1 left on rank 0's word, long before its own limit
 
 
 def test_tp2_product_forward_matches_tp1(dev):

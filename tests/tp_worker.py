@@ -261,13 +261,43 @@ def tp_model(rank: int, world: int, dev: torch.device) -> dict:
     return out
 
 
+def root_cause(rank: int, world: int, dev: torch.device) -> dict:
+    """World 3: rank 2 stays away; ranks 0 and 1 enter the same all-reduce, rank 0 with a short spin limit, rank 1
+    with a long one.  Rank 0 gives up first (waiting for rank 2) and tells its peers; rank 1 leaves its spin BECAUSE of that
+    word and must NOT tell anybody: rank 0's header keeps the root cause (no bit 20, the peer it waited for), rank 1's and
+    rank 2's headers hold rank 0's told copy (bit 20, rank field 0)."""
+    from mini_sglang_amd.kernel import P2PCommunicator
+
+    assert world == 3
+    comm = P2PCommunicator(rank, world, dist.group.WORLD, max_bytes=4 << 20, one_shot_max_bytes=256 << 10, blocks=8)
+    comm.set_spin_limit(100_000 if rank == 0 else 400_000_000)
+    x = torch.full((256 * 1024,), float(rank + 1), dtype=torch.bfloat16, device=dev)
+    comm.all_reduce(x)  # healthy round
+    torch.cuda.synchronize()
+    assert bool((x == 6.0).all())
+    dist.barrier()
+    res = {"world": world}
+    if rank != 2:
+        x = torch.ones(256 * 1024, dtype=torch.bfloat16, device=dev)
+        t0 = time.perf_counter()
+        comm.all_reduce(x)
+        torch.cuda.synchronize()
+        res["seconds"] = time.perf_counter() - t0
+        res["all_nan"] = bool(x.isnan().all())
+    dist.barrier()
+    time.sleep(0.2)
+    res["error_word"] = comm.error()
+    dist.barrier()
+    return res
+
+
 def main() -> None:
     mode, out_path = sys.argv[1], sys.argv[2]
     dev = torch.device(f"cuda:{sys.argv[3] if len(sys.argv) > 3 else 0}")
     rank, world, port = int(os.environ["RANK"]), int(os.environ["WORLD"]), int(os.environ["PORT"])
     torch.cuda.set_device(dev)
     dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    res = {"collectives": collectives, "tp_model": tp_model, "absent_rank": absent_rank}[mode](rank, world, dev)
+    res = {"collectives": collectives, "tp_model": tp_model, "absent_rank": absent_rank, "root_cause": root_cause}[mode](rank, world, dev)
     torch.save(res, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
