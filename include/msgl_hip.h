@@ -369,6 +369,28 @@ int msgl_g3_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K
                     int64_t ldo, int dtype, int grid, int full, int tail_split, int flags, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* Row-owner generation of the decode projection (csrc/gemm_ro.hip), 8 < M <= 256: the same `F.linear` of
+ * P/layers/linear.py:32,103,124 (and the LM head, P/layers/embedding.py:98).  The N / 16 sixteen-row units of `w` are cut
+ * into `tiles` balanced contiguous ranges (widths differ by at most one unit; at most msgl_ro_gemm_max_units(M) units each)
+ * and every range into `slices` k-slices; item (tile, slice) runs on workgroup (tile * slices + slice) % grid, grid = min(CU
+ * count, items).  Four loader waves per workgroup stream both operands by LDS-DMA through a three-stage ring, eight matrix
+ * waves run v_mfma_f32_16x16x32.  slices == 1: `out` [M, N] is written directly (a CU that owns whole rows of w: no split-K
+ * partial sums).  slices > 1: fp32 slabs [slices][M][N] in `workspace`, added in slice order by a reduce launch, or left to the
+ * consumer with MSGL_RO_SLABS_ONLY (msgl_fused_add_rmsnorm_slabs / msgl_qk_norm_rope_store_slabs, as msgl_m256_gemm_slabs_nt).
+ * `flags`:
+ *   MSGL_RO_SILU        slices == 1 only: `w` is a gate_up matrix in ops.interleave_gate_up order (as MSGL_G3_SILU), `out` is
+ *                       [M, N/2] = silu(gate) * up, bit-identical to this entry point without the flag followed by
+ *                       msgl_silu_and_mul_interleaved (P/layers/activation.py:9-12).
+ *   MSGL_RO_SLABS_ONLY  slices > 1 without the reduce launch; `out` unused.
+ * N % 16 == 0 (MSGL_RO_SILU: N % 64 == 0), K % 64 == 0.  Workspace: msgl_ro_gemm_workspace_bytes(M, N, slices). */
+#define MSGL_RO_SILU 1
+#define MSGL_RO_SLABS_ONLY 2
+int msgl_ro_gemm_max_units(int M);
+int64_t msgl_ro_gemm_workspace_bytes(int M, int N, int slices);
+int msgl_ro_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K, int64_t ldx, int64_t ldw,
+                    int64_t ldo, int dtype, int tiles, int slices, int flags, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Native radix prefix tree (libmsgl_hip.so, csrc/radix.cpp; host code, no device work).
  * Replaces: the tree walk of RadixPrefixCache -- _tree_walk, RadixTreeNode.split_at / get_match_len, lock_handle,

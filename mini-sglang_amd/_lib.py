@@ -103,6 +103,9 @@ HIP_SIGNATURES = {
     "msgl_m256_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
     "msgl_m256_gemm_slabs_nt": (_i, [_p, _p, _i, _i, _i, _l, _l, _i, _i, _i, _p, _l, _p]),
     "msgl_g3_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _i, _p, _l, _p]),
+    "msgl_ro_gemm_max_units": (_i, [_i]),
+    "msgl_ro_gemm_workspace_bytes": (_l, [_i, _i, _i]),
+    "msgl_ro_gemm_nt": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _i, _i, _i, _p, _l, _p]),
 }
 
 COMM_SIGNATURES = {

@@ -40,6 +40,7 @@ HIP_SOURCES = [
     "gemm_wstream.hip",
     "gemm_m256.hip",
     "gemm_g3.hip",
+    "gemm_ro.hip",
     "comm_p2p.hip",
 ]
 COMM_SOURCES = ["comm.cpp"]

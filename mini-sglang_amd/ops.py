@@ -914,6 +914,10 @@ def linear_silu(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = 
     gate_up_proj then act_fn): one fused launch where fused_silu_tune planned it, else linear + the activation kernel."""
     M, K = x.shape
     N = w.shape[0]
+    if _RO_SILU_PLAN:
+        plan = _RO_SILU_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return ro_linear(x, w, plan[0], 1, out, silu=True)
     if M <= SKINNY_MAX_M and _SKINNY_SILU_PLAN:
         plan = _SKINNY_SILU_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
@@ -953,6 +957,123 @@ def g3_linear(x: torch.Tensor, w: torch.Tensor, grid: int, full: int, tail_split
     return out
 
 
+# ---- row-owner generation (csrc/gemm_ro.hip), 8 < M <= 256: balanced 16-row-unit tiles x k-slices, plan = (tiles, slices)
+_RO_PLAN: dict = {}       # plan key -> (tiles, slices)
+_RO_SILU_PLAN: dict = {}  # plan key (w = interleaved gate_up) -> (tiles, 1): projection + SiLU.mul in one launch
+RO_SILU, RO_SLABS_ONLY = 1, 2
+RO_MIN_M, RO_MAX_M = 9, 256
+
+
+def ro_max_units(M: int) -> int:
+    """Units (16 weight rows) a tile may hold at this batch size (the accumulator budget of csrc/gemm_ro.hip)."""
+    return 9 if M > 128 else 18
+
+
+def ro_supported(M: int, N: int, K: int) -> bool:
+    return RO_MIN_M <= M <= RO_MAX_M and N % 16 == 0 and N >= 16 and K % 64 == 0 and K >= 64
+
+
+def ro_linear(x: torch.Tensor, w: torch.Tensor, tiles: int, slices: int, out: Optional[torch.Tensor] = None,
+              silu: bool = False) -> torch.Tensor:
+    """out[M, N] = x[M, K] @ w[N, K]^T by msgl_ro_gemm_nt with the plan (tiles, slices).  silu=True (slices == 1): `w` is a
+    gate_up weight in interleave_gate_up order and out[M, N/2] = silu(gate) * up."""
+    _need_cuda(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.dtype == w.dtype
+    assert x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    cols = N // 2 if silu else N
+    if out is None:
+        out = torch.empty((M, cols), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, cols) and out.stride(1) == 1 and out.dtype == x.dtype
+    _no_pending_slabs(x.device)
+    ws = gemm_workspace(x.device)
+    check(
+        lib().msgl_ro_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), out.stride(0),
+                              _dt(x), tiles, slices, RO_SILU if silu else 0, ws.data_ptr(), ws.numel(), _stream()),
+        "ro_gemm_nt",
+    )
+    return out
+
+
+def ro_candidates(M: int, N: int, K: int, cus: int, silu: bool = False):
+    """(tiles, slices) plans worth timing: items = tiles x slices close to one or two rounds of the CUs, every tile within the
+    accumulator budget; fewer, wider tiles (more k-slices) move less x per weight byte but more partial sums."""
+    units, nsteps, umax = N // 16, K // 64, ro_max_units(M)
+    min_tiles = -(-units // umax)
+    out = []
+
+    def add(tiles, slices):
+        tiles = max(min_tiles, min(tiles, units))
+        slices = max(1, min(slices, nsteps, 64))
+        if silu and slices != 1:
+            return
+        if slices > 1 and slices * M * N * 4 > GEMM_WORKSPACE_BYTES:
+            return
+        if (tiles, slices) not in out:
+            out.append((tiles, slices))
+
+    for rounds in (1, 2, 3):
+        items = rounds * cus
+        for slices in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+            tiles = items // slices
+            if tiles < min_tiles:
+                continue
+            if slices == 1 or tiles <= 4 * min_tiles:  # k-slicing only while the tiles stay reasonably wide
+                add(tiles, slices)
+    if not out:
+        add(min_tiles, 1)
+    return out
+
+
+def ro_tune(x: torch.Tensor, weights, incumbent_us: float, iters: int = 8) -> dict:
+    """Time the plans of ro_candidates on rotating weights, keep the fastest for this shape if it beats `incumbent_us` (the
+    best of the library and the other hand-written kernels) by PLAN_MARGIN."""
+    weights = list(weights)
+    w0 = weights[0]
+    M, K = x.shape
+    N = w0.shape[0]
+    res = dict(M=M, N=N, K=K, incumbent_us=incumbent_us, ro_us=None, plan=None, used=False)
+    key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    _RO_PLAN.pop(key, None)
+    if not ro_supported(M, N, K) or os.environ.get("MSGL_DISABLE_RO") == "1":
+        return res
+    cus = int(lib().msgl_device_cu_count())
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    ranked = sorted((_time_launches_us(lambda w: ro_linear(x, w, p[0], p[1], out), weights, iters, 1), p)
+                    for p in ro_candidates(M, N, K, cus))
+    best = min((_time_launches_us(lambda w: ro_linear(x, w, p[0], p[1], out), weights, iters, 3), p) for _, p in ranked[:4])
+    res.update(ro_us=best[0], plan=best[1], all={"/".join(map(str, p)): round(t, 1) for t, p in ranked})
+    if best[0] < PLAN_MARGIN * incumbent_us:
+        _RO_PLAN[key] = best[1]
+        res["used"] = True
+    return res
+
+
+def ro_silu_tune(x: torch.Tensor, weights, unfused_us: float, iters: int = 8) -> dict:
+    """gate_up in interleave_gate_up order: the row-owner launch with the activation in its epilogue against `unfused_us`
+    (whatever the search left for projection + activation).  One launch less in front of the same consumer: no margin asked."""
+    weights = list(weights)
+    w0 = weights[0]
+    M, K = x.shape
+    N = w0.shape[0]
+    res = dict(M=M, N=N, K=K, unfused_us=unfused_us, fused_us=None, plan=None, used=False)
+    key = (x.device.index or 0, M, N, K, x.stride(0), w0.stride(0), _dt(x))
+    _RO_SILU_PLAN.pop(key, None)
+    if not (ro_supported(M, N, K) and N % 64 == 0) or os.environ.get("MSGL_DISABLE_RO") == "1":
+        return res
+    cus = int(lib().msgl_device_cu_count())
+    half = torch.empty((M, N // 2), dtype=x.dtype, device=x.device)
+    ranked = sorted((_time_launches_us(lambda w: ro_linear(x, w, p[0], 1, half, silu=True), weights, iters, 1), p)
+                    for p in ro_candidates(M, N, K, cus, silu=True))
+    best = min((_time_launches_us(lambda w: ro_linear(x, w, p[0], 1, half, silu=True), weights, iters, 3), p) for _, p in ranked[:3])
+    res.update(fused_us=best[0], plan=best[1], all={"/".join(map(str, p)): round(t, 1) for t, p in ranked})
+    if best[0] < unfused_us:
+        _RO_SILU_PLAN[key] = best[1]
+        res["used"] = True
+    return res
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M, N] = x[M, K] @ w[N, K]^T (the reference's `F.linear`, P/layers/linear.py:32): the hand-written
     weight-streaming kernel where skinny_tune() planned it (decode batches <= 64), else msgl_gemm_nt with the
@@ -961,6 +1082,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None)
     if M == 0:
         return out
     _no_pending_slabs(x.device)
+    if _RO_PLAN:
+        plan = _RO_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            return ro_linear(x, w, plan[0], plan[1], out)
     if M >= M256_MIN_M and _M256_PLAN:
         plan = _M256_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
         if plan:
@@ -987,6 +1112,23 @@ def linear_slabs(x: torch.Tensor, w: torch.Tensor):
     shape's plan is the k-sliced full-batch kernel (or, mid-size batches, the k-split weight-streaming kernel), the reduce
     launch is left to the norm (slabs is a Slabs, `out` is allocated but NOT yet written: pass both to
     fused_add_rmsnorm_slabs); otherwise (out, None) = linear(x, w)."""
+    if _RO_PLAN:
+        M, K, N = x.shape[0], x.shape[1], w.shape[0]
+        plan = _RO_PLAN.get((x.device.index or 0, M, N, K, x.stride(0), w.stride(0), _dt(x)))
+        if plan:
+            if plan[1] == 1:
+                return linear(x, w), None
+            _no_pending_slabs(x.device)
+            out, M, N, K = _gemm_args(x, w, None)
+            ws = gemm_workspace(x.device)
+            check(
+                lib().msgl_ro_gemm_nt(None, x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), N, _dt(x), plan[0],
+                                      plan[1], RO_SLABS_ONLY, ws.data_ptr(), ws.numel(), _stream()),
+                "ro_gemm_nt(slabs)",
+            )
+            slabs = Slabs(ws.data_ptr(), plan[1], M, N, x.device.index or 0)
+            _PENDING_SLABS[slabs.device] = slabs
+            return out, slabs
     if x.shape[0] >= M256_MIN_M and _M256_PLAN:
         _no_pending_slabs(x.device)
         out, M, N, K = _gemm_args(x, w, None)
@@ -1124,6 +1266,8 @@ def reset_gemm_plans() -> None:
     _SKINNY_PLAN.clear()
     _WSTREAM_PLAN.clear()
     _M256_PLAN.clear()
+    _RO_PLAN.clear()
+    _RO_SILU_PLAN.clear()
     _FUSED_SILU_PLAN.clear()
     _SKINNY_SILU_PLAN.clear()
     _CANDIDATES.clear()
