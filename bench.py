@@ -507,7 +507,7 @@ def main() -> None:
     ap.add_argument("--no-prefill-roofline", action="store_true", help="skip the prefill-attention MFMA measurement")
     ap.add_argument("--no-second-config", action="store_true",
                     help="--gpus 4: skip the Qwen3-32B TP4 entry (the metric's second configuration)")
-    ap.add_argument("--small-batches", type=int, nargs="*", default=[1, 8, 32],
+    ap.add_argument("--small-batches", type=int, nargs="*", default=[1, 8, 32, 64, 128],
                     help="also report ms per decode step at these batch sizes (latency regime; [] to skip)")
     ap.add_argument("--rank-shard", type=int, default=0,
                     help="N > 1: time ONE rank's shard of a TP = N decode step on this GPU with the collectives looped back "

@@ -382,6 +382,8 @@ int msgl_g3_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K
  *                       [M, N/2] = silu(gate) * up, bit-identical to this entry point without the flag followed by
  *                       msgl_silu_and_mul_interleaved (P/layers/activation.py:9-12).
  *   MSGL_RO_SLABS_ONLY  slices > 1 without the reduce launch; `out` unused.
+ *   bits 8-15           diagnosis: 1 = no x loads, 2 = no MFMAs, 4 = no w loads (timing only, results meaningless); 8 / 16 = A/B variants of
+ *                       the matrix side with identical results; 0 in production.
  * N % 16 == 0 (MSGL_RO_SILU: N % 64 == 0), K % 64 == 0.  Workspace: msgl_ro_gemm_workspace_bytes(M, N, slices). */
 #define MSGL_RO_SILU 1
 #define MSGL_RO_SLABS_ONLY 2

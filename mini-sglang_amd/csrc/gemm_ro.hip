@@ -87,6 +87,8 @@ struct RoParams {
   const uint16_t* w;
   int M, N, nsteps, units, tiles, slices;
   int64_t ldx, ldw, ldo;
+  int abl;  // diagnosis (flags bits 8-15; 0 in production): 1 = no x loads, 2 = no LDS reads / MFMAs, 4 = no w loads,
+            // 8 = static wave priorities (measured neutral), 16 = read-all-then-multiply matrix body at M > 128 (A/B partner)
 };
 
 // s_waitcnt vmcnt takes an immediate: the number of DMA instructions a loader has in flight per step depends on the tile
@@ -142,6 +144,13 @@ __global__ __launch_bounds__(kRoThreads) void ro_gemm_kernel(const RoParams p) {
   const int items = p.tiles * p.slices;
   const int M = p.M;
 
+  if (p.abl & 8) {
+    // (experiment) static priorities: the loaders first, then matrix waves 0-3 over their SIMD partners 4-7, so that the two
+    // matrix waves of a SIMD fall out of lockstep (one multiplies while the other reads its fragments)
+    if (wv >= kRoMatrixWaves) __builtin_amdgcn_s_setprio(3);
+    else if (wv < 4) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   if (wv >= kRoMatrixWaves) {
     // =============================== loader wave ===============================
     const int L = wv - kRoMatrixWaves;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(kRoThreads) void ro_gemm_kernel(const RoParams p) {
       xvo[i] = min(row, M - 1) * (int)p.ldx * 2 + ((dchunk ^ ((row >> 1) & 7)) * 16);
       nx += (8 * P < M) ? 1 : 0;
     }
-    nx = sgpr(nx);
+    nx = sgpr((p.abl & 1) ? 0 : nx);
     const __amdgpu_buffer_rsrc_t xr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), (short)0, -1, 0x00020000);
     // w piece P = LDS rows [8 P, 8 P + 8) of the tile = half of unit P / 2; loader P % 4.  P & 1 = L & 1 for all of a loader's
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(kRoThreads) void ro_gemm_kernel(const RoParams p) {
           next_item += G;
           cstep = sgpr(it.s0);
           cend = sgpr(it.s1);
-          nw = sgpr(2 * it.ut > L ? (2 * it.ut - L + kRoLoaders - 1) / kRoLoaders : 0);
+          nw = sgpr(2 * it.ut > L && !(p.abl & 4) ? (2 * it.ut - L + kRoLoaders - 1) / kRoLoaders : 0);
           int base_row;
           if (EPI == RO_EPI_SILU)
             base_row = ro_silu_row(8 * it.u0, 0);
@@ -252,12 +261,72 @@ __global__ __launch_bounds__(kRoThreads) void ro_gemm_kernel(const RoParams p) {
 #pragma unroll
       for (int u = 0; u < UT; ++u) acc[b][u] = ro_f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (MTW == 2 && !(p.abl & (16 | 2))) {
+      // Software-pipelined body (a wave with one token tile only multiplies a second, never stored one: M > 128 here, so every
+      // wave has at least one): a half step's MFMAs run unit by unit, and as soon as a unit's two
+      // MFMAs have issued its fragment registers are reloaded with the NEXT half step's fragment of that unit -- the LDS reads
+      // of half step h + 1 travel under the MFMAs of half step h instead of in front of them (read-all-then-multiply leaves
+      // the two matrix waves of a SIMD in lockstep: both read, then both multiply: 70 us of matrix time for 40 us of MFMAs).
+      // The next STEP's fragments can only be requested after its barrier, which therefore sits between the two half steps;
+      // lgkmcnt(0) in front of it: every read of this stage has returned before the loaders may refill it.
+      U4 x0[2], x1[2], wa[kRoMaxUnits];
+      auto rx = [&](U4(&xf)[2], const unsigned char* base, int kh) __attribute__((always_inline)) {
+        xf[0] = *reinterpret_cast<const U4*>(base + x_off + fo[kh]);
+        xf[1] = *reinterpret_cast<const U4*>(base + x_off + kRoMatrixWaves * kRoUnitBytes + fo[kh]);
+      };
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned char* sb = smem + stage * S::kStage;
+      rx(x0, sb, 0);
+#pragma unroll
+      for (int u = 0; u < UT; ++u) wa[u] = *reinterpret_cast<const U4*>(sb + S::kXBytes + u * kRoUnitBytes + fo[0]);
+      // straight-line loop body (one basic block): every step but the last, then the last step without the look-ahead
+      for (int step = it.s0; step + 1 < it.s1; ++step) {
+        rx(x1, sb, 1);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          acc[0][u] = ro_mfma<T>(wa[u], x0[0], acc[0][u]);
+          acc[1][u] = ro_mfma<T>(wa[u], x0[1], acc[1][u]);
+          wa[u] = *reinterpret_cast<const U4*>(sb + S::kXBytes + u * kRoUnitBytes + fo[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+        sb = smem + stage * S::kStage;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rx(x0, sb, 0);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          acc[0][u] = ro_mfma<T>(wa[u], x1[0], acc[0][u]);
+          acc[1][u] = ro_mfma<T>(wa[u], x1[1], acc[1][u]);
+          wa[u] = *reinterpret_cast<const U4*>(sb + S::kXBytes + u * kRoUnitBytes + fo[0]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      rx(x1, sb, 1);
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        acc[0][u] = ro_mfma<T>(wa[u], x0[0], acc[0][u]);
+        acc[1][u] = ro_mfma<T>(wa[u], x0[1], acc[1][u]);
+        wa[u] = *reinterpret_cast<const U4*>(sb + S::kXBytes + u * kRoUnitBytes + fo[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        acc[0][u] = ro_mfma<T>(wa[u], x1[0], acc[0][u]);
+        acc[1][u] = ro_mfma<T>(wa[u], x1[1], acc[1][u]);
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+    } else
     for (int step = it.s0; step < it.s1; ++step) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const unsigned char* sb = smem + stage * S::kStage;
+      const int kh_end = (p.abl & 2) ? 0 : 2;  // (diagnosis: no LDS reads, no MFMAs)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
+        if (kh >= kh_end) break;
         // a half step: its fragments requested up front, the MFMAs follow as they arrive (LDS returns in order); the other
         // matrix wave of this SIMD multiplies meanwhile
         U4 xa[kRoMaxMTW], wa[kRoMaxUnits];
@@ -418,6 +487,7 @@ extern "C" int msgl_ro_gemm_nt(void* out, const void* x, const void* w, int M, i
   p.out = (uint16_t*)out; p.part = (float*)workspace; p.x = (const uint16_t*)x; p.w = (const uint16_t*)w;
   p.M = M; p.N = N; p.nsteps = nsteps; p.units = units; p.tiles = tiles; p.slices = slices;
   p.ldx = ldx; p.ldw = ldw; p.ldo = ldo;
+  p.abl = (flags >> 8) & 0xff;
   const int items = tiles * slices, cus = device_cu_count();
   const int grid = items < cus ? items : cus;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -98,6 +98,15 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                     r["skinny_used"] = True
                     r["kernel"] = ("msgl::%s[grid %d, whole tiles %d, k-slices %d]"
                                    % ((("m256_gemm_kernel", "g3_gemm_kernel")[mr["plan"][3]],) + tuple(mr["plan"][:3])))
+            if ops.ro_supported(bs, r["N"], r["K"]) and os.environ.get("MSGL_DISABLE_RO") != "1":
+                # row-owner generation (gemm_ro.hip): balanced 16-row-unit tiles x k-slices, against the best so far
+                rr = ops.ro_tune(x, ws, r["best_us"])
+                r.update(ro_us=rr["ro_us"], ro_plan=rr["plan"], ro_used=rr["used"], ro_all=rr.get("all"))
+                if rr["used"]:
+                    r.setdefault("library_best_us", r["best_us"])
+                    r["best_us"] = rr["ro_us"]
+                    r["skinny_used"] = True
+                    r["kernel"] = "msgl::ro_gemm_kernel[tiles %d, k-slices %d]" % tuple(rr["plan"])
             if flags.get("silu_interleaved") and (ops.m256_supported(bs, r["N"], r["K"]) or bs <= ops.SKINNY_MAX_M):
                 fr = ops.fused_silu_tune(x, ws)  # projection + activation as one launch vs the two just planned
                 r.update(silu_unfused_us=fr["unfused_us"], silu_fused_us=fr["fused_us"], silu_fused_plan=fr["plan"],
@@ -110,6 +119,18 @@ def tune_projection_gemms(groups: Sequence[Group], batch_sizes: Sequence[int], m
                         r["kernel"] = "msgl::skinny_gemm_kernel<silu>[slices %d, row tiles %d]" % tuple(fr["plan"])
                     else:
                         r["kernel"] = "msgl::g3_gemm_kernel<silu>[grid %d, whole tiles %d, k-slices %d]" % tuple(fr["plan"])
+            if flags.get("silu_interleaved") and ops.ro_supported(bs, r["N"], r["K"]) and os.environ.get("MSGL_DISABLE_RO") != "1":
+                # the row-owner launch with SiLU.mul in its epilogue against the best (projection, activation) pair or fused
+                # launch found so far
+                pair = r["best_us"] if (r.get("silu_fused_used")) else (r.get("silu_unfused_us") or ops.silu_pair_us(x, ws))
+                rs = ops.ro_silu_tune(x, ws, pair)
+                r.update(ro_silu_us=rs["fused_us"], ro_silu_plan=rs["plan"], ro_silu_used=rs["used"], ro_silu_all=rs.get("all"),
+                         ro_silu_against_us=pair)
+                if rs["used"]:
+                    r.setdefault("library_best_us", r["best_us"])
+                    r["best_us"] = rs["fused_us"]  # projection AND activation
+                    r["skinny_used"] = True
+                    r["kernel"] = "msgl::ro_gemm_kernel<silu>[tiles %d]" % rs["plan"][0]
             ops.register_candidates(name, x, ws[0], r)
             report.append(r)
             if log is not None:

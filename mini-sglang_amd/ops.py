@@ -961,7 +961,7 @@ def g3_linear(x: torch.Tensor, w: torch.Tensor, grid: int, full: int, tail_split
 _RO_PLAN: dict = {}       # plan key -> (tiles, slices)
 _RO_SILU_PLAN: dict = {}  # plan key (w = interleaved gate_up) -> (tiles, 1): projection + SiLU.mul in one launch
 RO_SILU, RO_SLABS_ONLY = 1, 2
-RO_MIN_M, RO_MAX_M = 9, 256
+RO_MIN_M, RO_MAX_M = 3, 256
 
 
 def ro_max_units(M: int) -> int:
@@ -974,7 +974,7 @@ def ro_supported(M: int, N: int, K: int) -> bool:
 
 
 def ro_linear(x: torch.Tensor, w: torch.Tensor, tiles: int, slices: int, out: Optional[torch.Tensor] = None,
-              silu: bool = False) -> torch.Tensor:
+              silu: bool = False, ablate: int = 0) -> torch.Tensor:
     """out[M, N] = x[M, K] @ w[N, K]^T by msgl_ro_gemm_nt with the plan (tiles, slices).  silu=True (slices == 1): `w` is a
     gate_up weight in interleave_gate_up order and out[M, N/2] = silu(gate) * up."""
     _need_cuda(x, w)
@@ -990,7 +990,7 @@ def ro_linear(x: torch.Tensor, w: torch.Tensor, tiles: int, slices: int, out: Op
     ws = gemm_workspace(x.device)
     check(
         lib().msgl_ro_gemm_nt(out.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0), w.stride(0), out.stride(0),
-                              _dt(x), tiles, slices, RO_SILU if silu else 0, ws.data_ptr(), ws.numel(), _stream()),
+                              _dt(x), tiles, slices, (RO_SILU if silu else 0) | (ablate << 8), ws.data_ptr(), ws.numel(), _stream()),
         "ro_gemm_nt",
     )
     return out
@@ -1013,7 +1013,8 @@ def ro_candidates(M: int, N: int, K: int, cus: int, silu: bool = False):
         if (tiles, slices) not in out:
             out.append((tiles, slices))
 
-    for rounds in (1, 2, 3):
+    r0 = -(-min_tiles // cus)  # the fewest whole rounds of the CUs the accumulator budget allows (LM head: 5)
+    for rounds in sorted({1, 2, 3, r0, r0 + 1}):
         items = rounds * cus
         for slices in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
             tiles = items // slices
@@ -1072,6 +1073,14 @@ def ro_silu_tune(x: torch.Tensor, weights, unfused_us: float, iters: int = 8) ->
         _RO_SILU_PLAN[key] = best[1]
         res["used"] = True
     return res
+
+
+def silu_pair_us(x: torch.Tensor, weights, iters: int = 8) -> float:
+    """Back-to-back time of what linear_silu does for this shape today (its planned fused launch, or projection + activation)."""
+    weights = list(weights)
+    N = weights[0].shape[0]
+    half = torch.empty((x.shape[0], N // 2), dtype=x.dtype, device=x.device)
+    return _time_launches_us(lambda w: linear_silu(x, w, half), weights, iters, 3)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -1208,10 +1217,18 @@ def register_candidates(name: str, x: torch.Tensor, w: torch.Tensor, report: dic
         cands.append((f"{('m256', 'g3')[plan[3]]} {plan[:3]} ({us:.1f} us)", ("hand", plan)))
     for lab, us in sorted((report.get("silu_fused_all") or {}).items(), key=lambda kv: kv[1])[:2]:
         cands.append((f"g3 fused SiLU.mul {lab} ({us:.1f} us)", ("fused", tuple(int(v) for v in lab.split("/")))))
+    for lab, us in sorted((report.get("ro_all") or {}).items(), key=lambda kv: kv[1])[:2]:
+        cands.append((f"ro {lab} ({us:.1f} us)", ("ro", tuple(int(v) for v in lab.split("/")))))
+    for lab, us in sorted((report.get("ro_silu_all") or {}).items(), key=lambda kv: kv[1])[:1]:
+        cands.append((f"ro fused SiLU.mul {lab} ({us:.1f} us)", ("ro_silu", tuple(int(v) for v in lab.split("/")))))
     _CANDIDATES[key] = dict(name=name, cands=cands, out_ld=w.shape[0])
 
 
 def current_candidate(key) -> str:
+    if key in _RO_SILU_PLAN:
+        return f"ro fused SiLU.mul {_RO_SILU_PLAN[key]}"
+    if key in _RO_PLAN and key not in _FUSED_SILU_PLAN:
+        return f"ro {_RO_PLAN[key]}"
     if key in _SKINNY_SILU_PLAN:
         return f"skinny fused SiLU.mul {_SKINNY_SILU_PLAN[key]}"
     if key in _FUSED_SILU_PLAN:
@@ -1230,26 +1247,37 @@ def apply_candidate(key, spec) -> None:
         _M256_PLAN.pop(key, None)
         _WSTREAM_PLAN.pop(key, None)
         _FUSED_SILU_PLAN.pop(key, None)
+        _RO_PLAN.pop(key, None)
+        _RO_SILU_PLAN.pop(key, None)
         _lib.check_gemm(_lib.gemm_lib().msgl_gemm_select_finalist(M, N, K, ldx, ldw, _CANDIDATES[key]["out_ld"], dt, int(arg)),
                         "gemm_select_finalist")
     elif kind == "hand":
         _FUSED_SILU_PLAN.pop(key, None)
+        _RO_PLAN.pop(key, None)
+        _RO_SILU_PLAN.pop(key, None)
         _M256_PLAN[key] = tuple(arg)
     elif kind == "fused":
+        _RO_SILU_PLAN.pop(key, None)
         _FUSED_SILU_PLAN[key] = tuple(arg)
+    elif kind == "ro":
+        _FUSED_SILU_PLAN.pop(key, None)
+        _RO_SILU_PLAN.pop(key, None)
+        _RO_PLAN[key] = tuple(arg)
+    elif kind == "ro_silu":
+        _RO_SILU_PLAN[key] = tuple(arg)
     else:
         raise ValueError(spec)
 
 
 def snapshot_plan(key):
     """Opaque state of the shape's hand-written plans (the library's pick is restored by index 0 of its finalists)."""
-    return (_M256_PLAN.get(key), _WSTREAM_PLAN.get(key), _FUSED_SILU_PLAN.get(key))
+    return (_M256_PLAN.get(key), _WSTREAM_PLAN.get(key), _FUSED_SILU_PLAN.get(key), _RO_PLAN.get(key), _RO_SILU_PLAN.get(key))
 
 
 def restore_search_pick(key, snap) -> None:
     """Back to what the back-to-back search left for the shape: its hand-written plans (`snap`) and, on the library
     side, the fastest finalist (= the search's own pick: the finalists are sorted by its times)."""
-    for d, v in zip((_M256_PLAN, _WSTREAM_PLAN, _FUSED_SILU_PLAN), snap):
+    for d, v in zip((_M256_PLAN, _WSTREAM_PLAN, _FUSED_SILU_PLAN, _RO_PLAN, _RO_SILU_PLAN), snap):
         if v is None:
             d.pop(key, None)
         else:

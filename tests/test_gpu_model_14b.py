@@ -44,7 +44,8 @@ def test_qwen3_14b_dims_full_decode_batch_with_tuned_plans_vs_oracle(dev):
         # the point of this test: the hand-written full-batch plans (not the library heuristic) carry the decode batch
         print("[14B dims] after the in-graph re-ranking: " + "; ".join(f"{r['name']}: {r['chosen']}" for r in eng.refine_report))
         assert eng.refine_report, "the in-graph re-ranking did not run (pool too small for its synthetic batch?)"
-        sliced = [k for k, p in ops._M256_PLAN.items() if k[1] == B and p[1] == 0 and p[2] > 1]
+        sliced = [k for k, p in ops._M256_PLAN.items() if k[1] == B and p[1] == 0 and p[2] > 1 and k not in ops._RO_PLAN]
+        sliced += [k for k, p in ops._RO_PLAN.items() if k[1] == B and p[1] > 1]
         assert len(sliced) >= 1, f"expected a k-sliced full-batch plan (slab hand-off) among the projections, got {chosen}"
         rnd = random.Random(0)
         prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(1, 8))] for _ in range(B)]
