@@ -515,6 +515,12 @@ int msgl_gemm_reset_plans(void);  /* forget all plans: shapes fall back to the l
  * inside a captured decode step they differ by up to 9 %, so the host re-ranks them in the step itself. */
 int msgl_gemm_finalists(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, float* us_out, int max_n);
 int msgl_gemm_select_finalist(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int index);
+/* A searched plan as data: (library solution index, split-K factor) of the shape -- get returns 1 / 0 (searched plan / none),
+ * set installs one without a search (fails if this library build lacks the index or the solution does not support the shape
+ * within workspace_bytes).  How one process's search result is replayed in another (tests/test_gpu_reference_driven.py). */
+int msgl_gemm_get_plan(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int* algo_index, int* split_k);
+int msgl_gemm_set_plan(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int algo_index, int split_k,
+                       void* workspace, int64_t workspace_bytes);
 int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype,
                             char* buf, int buf_len);
 const char* msgl_gemm_last_error(void);

@@ -131,6 +131,8 @@ GEMM_SIGNATURES = {
     "msgl_gemm_reset_plans": (_i, []),
     "msgl_gemm_finalists": (_i, [_i, _i, _i, _l, _l, _l, _i, C.POINTER(_f), _i]),
     "msgl_gemm_select_finalist": (_i, [_i, _i, _i, _l, _l, _l, _i, _i]),
+    "msgl_gemm_get_plan": (_i, [_i, _i, _i, _l, _l, _l, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "msgl_gemm_set_plan": (_i, [_i, _i, _i, _l, _l, _l, _i, _i, _i, _p, _l]),
     "msgl_gemm_last_error": (C.c_char_p, []),
 }
 

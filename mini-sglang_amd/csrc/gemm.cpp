@@ -485,6 +485,72 @@ int msgl_gemm_select_finalist(int M, int N, int K, int64_t ldx, int64_t ldw, int
   return MSGL_OK;
 }
 
+// The shape's current plan as (library solution index, split-K factor): returns 1 and fills the two if the shape has a
+// SEARCHED plan, 0 if it has none (heuristic / never seen).  With msgl_gemm_set_plan this carries one process's search result
+// into another process (the reference-driven parity tests replay a forward on exactly the plans its recorder ran).
+int msgl_gemm_get_plan(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int* algo_index, int* split_k) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  int rc = get_handle(&h, &dev);
+  if (rc != MSGL_OK) return rc;
+  auto it = g_plans.find(Key{dev, M, N, K, ldx, ldw, ldo, dtype});
+  if (it == g_plans.end() || !it->second.tuned) return 0;
+  if (algo_index) *algo_index = it->second.algo_index;
+  if (split_k) *split_k = it->second.split_k;
+  return 1;
+}
+
+// Make library solution `algo_index` (with split-K factor `split_k`, 0 = the solution's own) the shape's plan without a
+// search.  Fails if this library build does not know the index or the solution does not support the shape within
+// `workspace_bytes` of scratch.
+int msgl_gemm_set_plan(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, int algo_index, int split_k,
+                       void* workspace, int64_t workspace_bytes) {
+  GEMM_REQUIRE(M >= 1 && N >= 1 && K >= 1 && (dtype == MSGL_BF16 || dtype == MSGL_FP16) && algo_index >= 0 && split_k >= 0,
+               "gemm_set_plan: bad arguments");
+  std::lock_guard<std::mutex> lock(g_mu);
+  hipblasLtHandle_t h;
+  int dev;
+  int rc = get_handle(&h, &dev);
+  if (rc != MSGL_OK) return rc;
+  Plan pl;
+  pl.prob = std::make_shared<Problem>();
+  if ((rc = make_problem(pl.prob.get(), M, N, K, ldx, ldw, ldo, dtype)) != MSGL_OK) return rc;
+  std::vector<int> idx{algo_index};
+  std::vector<hipblasLtMatmulHeuristicResult_t> res;
+  GEMM_BLAS(hipblaslt_ext::getAlgosFromIndex(h, idx, res));
+  GEMM_REQUIRE(!res.empty(), "gemm_set_plan: the library has no solution with index %d", algo_index);
+  const float alpha = 1.0f, beta = 0.0f;
+  const size_t ws_bytes = (size_t)std::max<int64_t>(workspace_bytes, 0);
+  size_t need = 0;
+  pl.algo = res[0].algo;
+  if (split_k > 0) {
+    // the split-K object wants operand pointers at construction (the library refuses null ones); run() sets the real ones
+    // before every launch, so the caller's scratch buffer stands in for all three here
+    GEMM_REQUIRE(workspace != nullptr, "gemm_set_plan: a split-K plan needs the workspace pointer");
+    auto box = std::make_shared<GemmBox>();
+    new (box->raw) hipblaslt_ext::Gemm(h, pl.prob->desc, &alpha, workspace, pl.prob->a, workspace, pl.prob->b, &beta, workspace,
+                                       pl.prob->d, workspace, pl.prob->d);
+    box->live = true;
+    hipblaslt_ext::GemmTuning tuning;
+    tuning.setSplitK((uint16_t)split_k);
+    GEMM_REQUIRE(box->get()->isAlgoSupported(pl.algo, tuning, need) == HIPBLAS_STATUS_SUCCESS,
+                 "gemm_set_plan: solution %d does not support the shape with split-K %d", algo_index, split_k);
+    pl.box = box;
+  } else {
+    GEMM_REQUIRE(hipblaslt_ext::matmulIsAlgoSupported(h, pl.prob->desc, &alpha, pl.prob->a, pl.prob->b, &beta, pl.prob->d,
+                                                      pl.prob->d, pl.algo, need) == HIPBLAS_STATUS_SUCCESS,
+                 "gemm_set_plan: solution %d does not support the shape", algo_index);
+  }
+  GEMM_REQUIRE(need <= ws_bytes, "gemm_set_plan: solution %d needs %zu workspace bytes, %zu given", algo_index, need, ws_bytes);
+  pl.workspace = need;
+  pl.algo_index = algo_index;
+  pl.split_k = split_k;
+  pl.tuned = true;
+  g_plans[Key{dev, M, N, K, ldx, ldw, ldo, dtype}] = pl;
+  return MSGL_OK;
+}
+
 int msgl_gemm_solution_name(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldo, int dtype, char* buf,
                             int buf_len) {
   GEMM_REQUIRE(buf && buf_len > 0, "gemm_solution_name: bad buffer");

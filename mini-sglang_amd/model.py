@@ -72,6 +72,9 @@ PRESETS: Dict[str, ModelConfig] = {
     "tiny": ModelConfig(2, 10, 2, 128, 256, 1024, 512, max_position=4096, name="tiny"),
     "tiny-llama": ModelConfig(2, 8, 2, 128, 256, 1024, 512, rms_norm_eps=1e-5, qk_norm=False, max_position=4096,
                               name="tiny-llama"),
+    # Qwen3-14B's layer at full width (every projection has the real decode shapes, so the searched plans are the real ones),
+    # two layers and a 32 k vocabulary: 2 GB of weights -- small enough to write as a checkpoint in a test
+    "qwen3-14b-width-2l": ModelConfig(2, 40, 8, 128, 5120, 32768, 17408, max_position=4096, name="Qwen3-14B width, 2 layers"),
 }
 
 

@@ -1288,6 +1288,43 @@ def restore_search_pick(key, snap) -> None:
                         "gemm_select_finalist")
 
 
+_PLAN_TABLES = {"skinny": _SKINNY_PLAN, "skinny_silu": _SKINNY_SILU_PLAN, "wstream": _WSTREAM_PLAN, "m256": _M256_PLAN,
+                "fused_silu": _FUSED_SILU_PLAN, "ro": _RO_PLAN, "ro_silu": _RO_SILU_PLAN}
+
+
+def export_gemm_plans(shapes) -> dict:
+    """Every per-shape kernel choice of this process as plain data: the hand-written kernels' plan tables and, for each
+    (M, N, K, ldx, ldw, ldo, dtype code) in `shapes`, the library's searched solution (index, split-K).  import_gemm_plans in
+    another process then runs `linear` / `linear_silu` / `linear_slabs` on exactly the same kernels."""
+    import ctypes as C
+
+    tables = {n: {repr(k): list(v) for k, v in t.items()} for n, t in _PLAN_TABLES.items()}
+    library = []
+    for (M, N, K, ldx, ldw, ldo, dt) in shapes:
+        idx, sk = C.c_int(-1), C.c_int(0)
+        rc = _lib.gemm_lib().msgl_gemm_get_plan(M, N, K, ldx, ldw, ldo, dt, C.byref(idx), C.byref(sk))
+        _lib.check_gemm(rc, "gemm_get_plan")
+        if rc == 1:
+            library.append([M, N, K, ldx, ldw, ldo, dt, idx.value, sk.value])
+    return dict(tables=tables, library=library)
+
+
+def import_gemm_plans(plans: dict, device_index: int = 0, reset: bool = True) -> None:
+    """Install what export_gemm_plans recorded (plan keys are re-targeted at `device_index`); reset: drop everything else first."""
+    import ast
+
+    if reset:
+        reset_gemm_plans()
+    for name, table in plans["tables"].items():
+        for k, v in table.items():
+            key = ast.literal_eval(k)
+            _PLAN_TABLES[name][(device_index,) + tuple(key[1:])] = tuple(v)
+    ws = gemm_workspace(torch.device("cuda", device_index))
+    for M, N, K, ldx, ldw, ldo, dt, idx, sk in plans["library"]:
+        _lib.check_gemm(_lib.gemm_lib().msgl_gemm_set_plan(M, N, K, ldx, ldw, ldo, dt, idx, sk, ws.data_ptr(), ws.numel()),
+                        "gemm_set_plan")
+
+
 def reset_gemm_plans() -> None:
     """Drop every per-shape kernel choice made so far in this process (hand-written kernel plans and library
     solutions): `linear` is the library's heuristic again until the next search."""

@@ -41,6 +41,7 @@ DIMS = {
     "qwen3-0.6b": (28, 1024, 16, 8, 128, 3072, 151936, True),
     "qwen3-14b": (40, 5120, 40, 8, 128, 17408, 151936, False),
     "qwen3-32b": (64, 5120, 64, 8, 128, 25600, 151936, False),
+    "qwen3-14b-width-2l": (2, 5120, 40, 8, 128, 17408, 32768, False),   # model.PRESETS: the 14B layer at full width, 2 GB
 }
 
 

@@ -407,6 +407,16 @@ def main() -> None:
                                                     "_msgl_fused", False)),
                gemm_report=plugin.gemm_report(), refine_report=plugin._STATE.get("refine_report", []), prefix_cache=type(cm.prefix_cache).__name__, deferred_reduce_weights=len(plugin._STATE["deferred_reduce_weights"]), free_pages_end=int(len(cm.free_slots)),
                evictable_end=int(cm.prefix_cache.size_info.evictable_size), device=torch.cuda.get_device_name(0))
+    if spec.get("export_gemm_plans"):
+        # the search's result as data (hand-written kernels' plan tables + the library's picks per searched shape): the test
+        # process installs exactly these plans in its own engine before it replays the recorded forwards
+        from mini_sglang_amd import ops as _ops
+
+        code = _ops._dt(torch.empty(0, dtype=torch.bfloat16))
+        shapes = [(r["M"], r["N"], r["K"], r["K"], r["K"], r["N"], code) for r in plugin.gemm_report()]
+        shapes += [(r["M"], r["N"], r["K"], r["K"], r["K"], r["N"] // 2, code) for r in plugin.gemm_report()]
+        rec["gemm_plans"] = _ops.export_gemm_plans(shapes)
+        rec["plan_labels"] = {f"{r['name']}@{r['M']}": r["kernel"][:90] for r in plugin.gemm_report()}
     rec["tp_rank"], rec["tp_size"] = tp_rank, tp_size
     if tp_size > 1:
         import minisgl.distributed.impl as dimpl
