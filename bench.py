@@ -161,10 +161,13 @@ def gemm_traffic_over_algorithmic():
         f, w = json.loads(fp.read_text()), json.loads(wp.read_text())
     except Exception:
         return None, None
-    ops_ = [k for k in f["per_launch"] if not k.startswith("gate_up g3") and not k.startswith("tail reduce")]
-    moved = sum(2.0 * f["per_launch"][k]["FETCH_SIZE"] + w["per_launch"][k]["WRITE_SIZE"] for k in ops_) * 1024.0
     man = f["manifest"]
-    algo = sum(man["algorithmic_bytes"].values()) + 2 * man["norm_algorithmic_bytes"] + man["silu_algorithmic_bytes"]
+    if "path_ops" in man:  # round 5 on: the manifest names the launches of the step's path and their algorithmic bytes
+        ops_, algo = man["path_ops"], man["path_algorithmic_bytes"]
+    else:
+        ops_ = [k for k in f["per_launch"] if not k.startswith("gate_up g3") and not k.startswith("tail reduce")]
+        algo = sum(man["algorithmic_bytes"].values()) + 2 * man["norm_algorithmic_bytes"] + man["silu_algorithmic_bytes"]
+    moved = sum(2.0 * f["per_launch"][k]["FETCH_SIZE"] + w["per_launch"][k]["WRITE_SIZE"] for k in ops_) * 1024.0
     return moved / algo, f"profiles/{fp.name} + {wp.name}"
 
 

@@ -193,3 +193,25 @@ def test_synthetic_qwen_trace_is_deterministic_and_in_range():
     assert all(x["t"] <= y["t"] for x, y in zip(a, a[1:]))
     assert all(16 <= r["input_length"] <= 6000 and 8 <= r["output_length"] <= 1000 for r in a)
     assert 5.0 < a[-1]["t"] < 20.0  # ~50 arrivals at 5 / s
+
+
+def test_ro_plan_arithmetic_matches_the_kernel_and_covers_every_unit():
+    """Host side of the row-owner projection (csrc/gemm_ro.hip): the Python accumulator budget equals the library's, every
+    candidate plan respects it, and the balanced tile cut the kernel computes (tile t = units [t U / T, (t + 1) U / T)) covers
+    every 16-row unit exactly once with widths that differ by at most one."""
+    from mini_sglang_amd import _lib, ops
+
+    for M in (3, 16, 64, 128, 129, 200, 256):
+        assert _lib.lib().msgl_ro_gemm_max_units(M) == ops.ro_max_units(M)
+    for (M, N, K) in [(256, 34816, 5120), (256, 5120, 17408), (128, 7168, 5120), (64, 151936, 5120), (9, 16, 64), (200, 2064, 640),
+                      (256, 8704, 5120), (256, 1792, 5120)]:
+        units, umax = N // 16, ops.ro_max_units(M)
+        cands = ops.ro_candidates(M, N, K, 256)
+        assert cands, (M, N, K)
+        for tiles, slices in cands:
+            cut = [t * units // tiles for t in range(tiles + 1)]
+            widths = [b - a for a, b in zip(cut[:-1], cut[1:])]
+            assert cut[0] == 0 and cut[-1] == units and min(widths) >= 1 and max(widths) <= umax, (M, N, K, tiles)
+            assert max(widths) - min(widths) <= 1 and 1 <= slices <= K // 64
+        assert all(s == 1 for _, s in ops.ro_candidates(M, N, K, 256, silu=True))
+    assert _lib.lib().msgl_ro_gemm_workspace_bytes(256, 5120, 6) == 6 * 256 * 5120 * 4

@@ -523,3 +523,31 @@ def test_prefill_chunk_gemm_search_keeps_results_and_records_a_plan(dev):
         assert (got - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
     finally:
         ops.reset_gemm_plans()
+
+
+def test_searched_plans_travel_as_data(ops, dev):
+    """ops.export_gemm_plans / import_gemm_plans (msgl_gemm_get_plan / msgl_gemm_set_plan): the library solution a search picked
+    -- plain and split-K -- and the hand-written kernels' plan tables, exported, dropped and re-installed: `linear` gives the same
+    bits as before (how tests/test_gpu_reference_driven.py replays a reference-driven run on its recorder's plans)."""
+    g = torch.Generator(device=dev).manual_seed(21)
+    code = ops._dt(torch.empty(0, dtype=torch.bfloat16))
+    try:
+        cases = []
+        for (M, N, K) in [(256, 5120, 17408), (3, 5120, 5120), (64, 2048, 1024)]:
+            x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
+            ws = [(torch.randn((N, K), generator=g, device=dev) * 0.05).to(torch.bfloat16) for _ in range(2)]
+            ops.gemm_tune(x, ws, max_candidates=-8, iters=2)
+            cases.append((x, ws[0], ops.linear(x, ws[0]).clone()))
+        key = (dev.index or 0, 64, 2048, 1024, 1024, 1024, code)
+        ops._RO_PLAN[key] = (16, 2)
+        cases[2] = cases[2][:2] + (ops.linear(*cases[2][:2]).clone(),)
+        plans = ops.export_gemm_plans([(x.shape[0], w.shape[0], x.shape[1], x.shape[1], x.shape[1], w.shape[0], code) for x, w, _ in cases])
+        assert len(plans["library"]) == 3 and plans["tables"]["ro"]
+        ops.reset_gemm_plans()
+        assert not ops._RO_PLAN
+        ops.import_gemm_plans(plans, dev.index or 0)
+        assert ops._RO_PLAN[key] == (16, 2)
+        for x, w, want in cases:
+            assert torch.equal(ops.linear(x, w), want)
+    finally:
+        ops.reset_gemm_plans()

@@ -1,3 +1,5 @@
+"""A searched library solution carried to another plan table as data (ops.export_gemm_plans / import_gemm_plans over
+msgl_gemm_get_plan / msgl_gemm_set_plan): same bits before and after, plain and split-K solutions.  python tools/gemm_plan_roundtrip.py"""
 import sys, torch, ctypes as C
 sys.path.insert(0, "/root/repo")
 from mini_sglang_amd import ops, _lib

@@ -4,9 +4,10 @@
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_g_FETCH_SIZE -- python tools/pmc_gemm.py --manifest gpurun_out/pmc_gemm_manifest.json
     python tools/pmc_gemm_summary.py <results.db> gpurun_out/pmc_gemm_manifest.json
 
-Every launch streams a different layer's weights (8 rotating buffers per shape); plans = what the pre-capture search
-picks at M = 256 (k-sliced g3 / m256 kernels leave fp32 slabs, consumed by the fused-add RMSNorm resp. the
-qk-norm/RoPE/store pass, exactly as in the captured decode step).  Three 1-GiB device copies first: the FETCH_SIZE
+Every launch streams a different layer's weights (8 rotating buffers per shape); plans = what the pre-capture search and the
+in-graph re-ranking pick at M = 256 (round 5: row-owner kernel for qkv and for gate_up with the SiLU.mul epilogue, k-sliced g3
+for o / down; k-sliced launches leave fp32 slabs, consumed by the fused-add RMSNorm resp. the qk-norm/RoPE/store pass, exactly
+as in the captured decode step).  Three 1-GiB device copies first: the FETCH_SIZE
 calibration (gfx950 reports half of a wide streaming read).  The manifest lists the launches in order with their
 algorithmic bytes so that the summary can attribute dispatches of the same kernel name to the right projection.
 """
@@ -43,12 +44,15 @@ def main():
     W = dict(qkv=ws((hq + 2 * hkv) * D, H), o=ws(H, hq * D), gate_up=ws(2 * inter, H, 4), down=ws(H, inter, 4))
     N = dict(qkv=(hq + 2 * hkv) * D, o=H, gate_up=2 * inter, down=H)
     K = dict(qkv=H, o=hq * D, gate_up=H, down=inter)
-    # FIXED plans (a timing search under the profiler picks different kernels in every pass): what the search picks
-    # un-profiled on this model -- k-sliced g3 for qkv / o / down, the library for gate_up -- plus the hand-written
-    # gate_up variants the search rejects, for comparison
+    # FIXED plans (a timing search under the profiler picks different kernels in every pass): what the search + the in-graph
+    # re-ranking pick un-profiled on this model in round 5 (profiles/r05*_bench*.json): qkv = row-owner kernel, 85 tiles x 3
+    # k-slices (slabs -> the qk-norm / RoPE / store pass); o and down = g3, 6 k-slices (slabs -> the fused-add RMSNorm);
+    # gate_up = row-owner kernel, one tile per CU, SiLU.mul in the epilogue.  For comparison, outside the step's path: the
+    # library's gate_up + the activation kernel (round 4's path), the row-owner kernel on o / down.
     dt = ops._dt(torch.empty(0, dtype=bf))
-    for name, split in (("qkv", 4), ("o", 6), ("down", 6)):
+    for name, split in (("o", 6), ("down", 6)):
         ops._M256_PLAN[(0, M, N[name], K[name], K[name], K[name], dt)] = (256, 0, split, 1)
+    ops._RO_PLAN[(0, M, N["qkv"], K["qkv"], K["qkv"], K["qkv"], dt)] = (85, 3)
     x = {k: torch.randn((M, v), device=dev).to(bf) for k, v in K.items()}
     res = torch.randn((M, H), device=dev).to(bf)
     nw = torch.ones(H, device=dev, dtype=bf)
@@ -60,10 +64,12 @@ def main():
     loc = torch.arange(M, device=dev, dtype=torch.int32)
     wi = [ops.interleave_gate_up(w) for w in W["gate_up"]]
     half = torch.empty((M, inter), device=dev, dtype=bf)
+    full = torch.empty((M, H), device=dev, dtype=bf)
     # warm every path once (code objects, library heuristics) before the measured region
     ops.silu_and_mul(ops.linear(x["gate_up"], W["gate_up"][0]))
-    ops.g3_linear(x["gate_up"], wi[0], 256, 256, 16, out=half, silu=True)
-    ops.g3_linear(x["gate_up"], wi[0], 256, 256, 16)
+    ops.ro_linear(x["gate_up"], wi[0], 256, 1, half, silu=True)
+    ops.ro_linear(x["o"], W["o"][0], 51, 5, full)
+    ops.ro_linear(x["down"], W["down"][0], 42, 6, full)
     torch.cuda.synchronize()
     a1 = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
     b1 = torch.empty_like(a1)
@@ -75,30 +81,41 @@ def main():
     def algo(n, k):
         return 2 * n * k + 2 * M * k + 2 * M * n
 
+    path = ["qkv ro 85 tiles x 3 k-slices (slabs)", "qk-norm/RoPE/store reading 3 slabs", "o g3 6 k-slices (slabs)",
+            "fused-add RMSNorm reading 6 slabs", "gate_up ro 256 tiles, SiLU.mul epilogue", "down g3 6 k-slices (slabs)",
+            "fused-add RMSNorm reading 6 slabs (after down)"]
     for rep in range(a.reps):
         w = W["qkv"][rep % len(W["qkv"])]
         qkv, slabs = ops.linear_slabs(x["qkv"], w)
         ops.qk_norm_rope_store_slabs(qkv, slabs, hq, hkv, qw, qw, 1e-6, pos, cos_sin, kc, vc, loc, D)
-        expected += [("qkv g3 4 k-slices (slabs)", "gemm"), ("qk-norm/RoPE/store reading 4 slabs", "qk")]
+        expected += [(path[0], "gemm"), (path[1], "qk")]
         w = W["o"][rep % len(W["o"])]
         y, slabs = ops.linear_slabs(x["o"], w)
         ops.fused_add_rmsnorm_slabs(y, res, nw, 1e-6, slabs)
-        expected += [("o g3 6 k-slices (slabs)", "gemm"), ("fused-add RMSNorm reading 6 slabs", "norm")]
-        w = W["gate_up"][rep % len(W["gate_up"])]
-        act = ops.silu_and_mul(ops.linear(x["gate_up"], w))
-        expected += [("gate_up library (heuristic solution)", "gemm"), ("SiLU.mul", "silu")]
+        expected += [(path[2], "gemm"), (path[3], "norm")]
+        act = ops.ro_linear(x["gate_up"], wi[rep % len(wi)], 256, 1, half, silu=True)
+        expected += [(path[4], "gemm")]
         w = W["down"][rep % len(W["down"])]
         y, slabs = ops.linear_slabs(act, w)
         ops.fused_add_rmsnorm_slabs(y, res, nw, 1e-6, slabs)
-        expected += [("down g3 6 k-slices (slabs)", "gemm"), ("fused-add RMSNorm reading 6 slabs (after down)", "norm")]
-        ops.g3_linear(x["gate_up"], wi[rep % len(wi)], 256, 256, 16, out=half, silu=True)
-        expected += [("gate_up g3 fused SiLU.mul 256 whole + 16 tail tiles x 16 slices", "gemm"), ("tail reduce + SiLU.mul", "reduce")]
+        expected += [(path[5], "gemm"), (path[6], "norm")]
+        # comparison launches (not part of the step's path)
+        ops.silu_and_mul(ops.linear(x["gate_up"], W["gate_up"][rep % len(W["gate_up"])]))
+        expected += [("(comparison) gate_up library (heuristic solution)", "gemm"), ("(comparison) SiLU.mul", "silu")]
+        ops.ro_linear(x["o"], W["o"][rep % len(W["o"])], 51, 5, full)
+        expected += [("(comparison) o ro 51 tiles x 5 k-slices", "gemm"), ("(comparison) o ro reduce launch", "reduce")]
+        ops.ro_linear(act, W["down"][rep % len(W["down"])], 42, 6, full)
+        expected += [("(comparison) down ro 42 tiles x 6 k-slices", "gemm"), ("(comparison) down ro reduce launch", "reduce")]
     torch.cuda.synchronize()
-    sizes = {"qkv": algo(N["qkv"], K["qkv"]), "o": algo(N["o"], K["o"]), "gate_up": algo(N["gate_up"], K["gate_up"]),
+    sizes = {"qkv": algo(N["qkv"], K["qkv"]), "o": algo(N["o"], K["o"]),
+             "gate_up": 2 * N["gate_up"] * K["gate_up"] + 2 * M * K["gate_up"] + 2 * M * inter,   # fused: writes [M, inter]
              "down": algo(N["down"], K["down"])}
     manifest = dict(reps=a.reps, expected=expected, algorithmic_bytes=sizes,
                     weight_bytes={k: 2 * N[k] * K[k] for k in N}, x_bytes={k: 2 * M * K[k] for k in K},
-                    norm_algorithmic_bytes=4 * M * H * 2, silu_algorithmic_bytes=3 * M * inter * 2)
+                    norm_algorithmic_bytes=4 * M * H * 2, silu_algorithmic_bytes=3 * M * inter * 2,
+                    # the step's projection path and its algorithmic bytes: weights + activations in / out of the four
+                    # projections, the two fused-add norms (x and residual in and out); the qk pass works in place on qkv
+                    path_ops=path, path_algorithmic_bytes=sum(sizes.values()) + 2 * (4 * M * H * 2))
     Path(a.manifest).parent.mkdir(parents=True, exist_ok=True)
     Path(a.manifest).write_text(json.dumps(manifest, indent=1))
 

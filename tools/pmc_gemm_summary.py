@@ -14,7 +14,7 @@ from collections import defaultdict
 def kind(n):
     if "reduce_kernel" in n:
         return "reduce"
-    if "g3_gemm_kernel" in n or "m256_gemm_kernel" in n or "wstream_gemm" in n or "Cijk_" in n:
+    if "g3_gemm_kernel" in n or "m256_gemm_kernel" in n or "wstream_gemm" in n or "ro_gemm_kernel" in n or "Cijk_" in n:
         return "gemm"
     if "qk_norm_rope_store" in n:
         return "qk"

@@ -1,3 +1,6 @@
+"""Row-owner kernel (csrc/gemm_ro.hip): same-process A/B of its matrix side at M > 128 -- the software-pipelined body (default)
+against read-all-then-multiply (flag bit 16 << 8), with and without the loads (ablation bits) -- bit equality of the two bodies
+first.  python tools/ro_matrix_ab.py"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from mini_sglang_amd import ops
@@ -10,8 +13,8 @@ for name, M, N, K, plan in [("gate_up", 256, 34816, 5120, (256, 1)), ("gate_up",
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     r = {}
     same = torch.equal(ops.ro_linear(x, ws[0], plan[0], plan[1]), ops.ro_linear(x, ws[0], plan[0], plan[1], ablate=16))
-    r["pipelined == base bits"] = same
+    r["both bodies give the same bits"] = same
     for rep in range(2):
-        for label, abl in [("base", 0), ("pipelined", 16), ("mfma-only", 5), ("mfma-only pipelined", 21)]:
+        for label, abl in [("pipelined (default)", 0), ("read-all-then-multiply", 16), ("no loads, pipelined", 5), ("no loads, read-all-then-multiply", 21)]:
             r.setdefault(label, []).append(round(time_us(lambda w: ops.ro_linear(x, w, plan[0], plan[1], out, ablate=abl), ws), 1))
     print(name, M, r, flush=True)
