@@ -391,9 +391,13 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
                                      be.max_bs, be.capacity, be.scale, slot_run=be.slot_run)
     for _ in range(3):
         launch()
-    # one event pair per launch (attention kernel + merge kernel), synchronised: what rocprofv3's per-kernel durations of
-    # the same command add up to.  (Thirty launches behind one event pair overlap the dispatch of launch i + 1 with the
-    # tail of launch i and read ~4 % lower than the kernel trace.)
+    # Two measurements of one layer's launch (attention kernel + merge kernel), both with HIP events on the launch stream:
+    #  * busy stream (`us_per_launch`, what `achieved` uses): 30 launches queued back to back with an event after each, the
+    #    median distance between consecutive events -- how the launch runs inside the decode step, where the stream never
+    #    idles (rocprofv3 of the timed steps: 173.6 + 6.3 us per layer in round 5, profiles/r05_bench_timed_steps_*.txt;
+    #    this figure is within ~2 % of it);
+    #  * idle stream (`us_per_launch_idle_stream`): one synchronised event pair per launch, the method of rounds 1-4 -- it adds
+    #    the host-to-idle-GPU launch latency to every sample (5-8 % above the kernel trace, box dependent).
     reps, tot = 30, 0.0
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -402,7 +406,17 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
         e1.record()
         e1.synchronize()
         tot += e0.elapsed_time(e1)
-    attn_us = tot * 1e3 / reps  # partial + merge kernels of one layer
+    attn_us_idle = tot * 1e3 / reps
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 4)]
+    for _ in range(3):
+        launch()
+    evs[0].record()
+    for i in range(reps + 3):
+        launch()
+        evs[i + 1].record()
+    evs[-1].synchronize()
+    gaps = sorted(x.elapsed_time(y) for x, y in zip(evs[3:-1], evs[4:]))  # the first three gaps = ramp of the queue
+    attn_us = gaps[len(gaps) // 2] * 1e3  # partial + merge kernels of one layer
     S = sum(lens_now)
     attn_bytes = S * 2 * hkv * D * it + 2 * B * hq * D * it + S * 4 + 2 * B * 4
     achieved = attn_bytes / attn_us / 1e3
@@ -456,6 +470,7 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
             "bound": "hbm", "kernel": "attn_decode_mfma_kernel (+merge), one layer", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_source": traffic_src, "traffic_over_algorithmic": traffic_ratio, "us_per_launch": attn_us,
+            "us_per_launch_idle_stream": attn_us_idle, "timing": "median distance of consecutive HIP events over 30 launches queued back to back (busy stream, as inside the step); idle_stream = one synchronised event pair per launch (rounds 1-4)",
             "algorithmic_bytes": attn_bytes, "launch_shape": shape,
         },
         "prefill_roofline": prefill_roofline,
