@@ -2,7 +2,7 @@
 reference's `F.linear` (P/layers/linear.py:32,103,124; P/layers/embedding.py:98):
 
   * every plan (tiles, k-slices) of the search + adversarial ones (one tile, ragged widths, more items than CUs, every M
-    class: 9 .. 256, partial token tiles) within atol = 2^-7 * max|ref| of x.float() @ w.float().T (bf16 output rounding
+    class: 3 .. 256, partial token tiles) within atol = 2^-7 * max|ref| of x.float() @ w.float().T (bf16 output rounding
     2^-9 relative plus the accumulation-order term; the same bound tests/test_gpu_gemm.py writes for every other GEMM path);
   * the result of a row does not depend on the batch it is in, on the tile cut, or on the launch (bit equality);
   * rows past M are never written; the k-sliced plans' slabs added in slice order by the kernel's own reduce launch equal
@@ -43,7 +43,8 @@ def _plans(ops, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(256, 5120, 5120), (256, 7168, 1024), (256, 34816, 512), (200, 2064, 640), (129, 144, 64),
                                    (128, 5120, 2048), (128, 34816, 256), (100, 7168, 512), (64, 1024, 17408), (48, 4352, 320),
-                                   (17, 288, 128), (9, 16, 64), (16, 151936, 128), (136, 1008, 192)])
+                                   (17, 288, 128), (9, 16, 64), (16, 151936, 128), (136, 1008, 192), (3, 5120, 5120), (8, 34816, 512),
+                                   (4, 7168, 1024)])
 def test_ro_gemm_matches_fp32_reference(ops, dev, M, N, K):
     g = torch.Generator(device=dev).manual_seed(M * 31 + N + K)
     x = (torch.randn((M, K), generator=g, device=dev) * 0.5).to(torch.bfloat16)
@@ -103,7 +104,7 @@ def test_ro_identity_fp16_strided_operands_and_argument_checks(ops, dev):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,inter,K,tiles", [(256, 17408, 5120, 256), (256, 1024, 512, 16), (200, 3072, 1024, 100), (129, 512, 640, 8),
-                                             (128, 17408, 1024, 256), (64, 4352, 512, 31), (24, 64, 64, 1), (9, 2048, 128, 256)])
+                                             (128, 17408, 1024, 256), (64, 4352, 512, 31), (24, 64, 64, 1), (9, 2048, 128, 256), (4, 17408, 512, 256)])
 def test_ro_fused_silu_equals_projection_then_activation(ops, dev, dtype, M, inter, K, tiles):
     """gate_up_proj + silu_and_mul (P/models/utils.py:45-51) as ONE launch on the interleaved weight: bit-identical to the
     projection rounded to 16 bits followed by the activation kernel; against the fp32 oracle within the activation's bound."""
