@@ -83,6 +83,14 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
     w = ref_model.random_weights(
         type("C", (), dict(cfg.__dict__, vocab_size=small_vocab, tie_word_embeddings=True))(), torch.float32, num_layers=L)
     w.lm_head = torch.randn((cfg.vocab_size, cfg.hidden_size), generator=g) * 0.02
+    # bf16 weights, fp32 accumulation: every weight rounded to bf16, held and multiplied as fp32
+    # (torch's CPU bf16 matmul is several times slower than its fp32 one on these hosts and would flatter the GPU)
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    w.embed, w.final_norm, w.lm_head = bf(w.embed), bf(w.final_norm), bf(w.lm_head)
+    for lw in w.layers:
+        for k_, v_ in list(lw.items()):
+            if torch.is_tensor(v_) and v_.is_floating_point():
+                lw[k_] = bf(v_)
     row = max(lens) + rounds + 2
     table = torch.arange(B * row, dtype=torch.int32).view(B, row)
     kp = [torch.randn((B * row, cfg.num_kv_heads, D), generator=g) for _ in range(L)]
@@ -100,7 +108,7 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
     # thread count: torch-eager on a many-core host is not monotone in threads (the per-request attention loop and the
     # M = 256 GEMMs want different counts; 64 threads measured 3.5x SLOWER per layer than 8 on one box): one layer at each
     # of a few counts, the fastest is the baseline's (and is what `cores` reports)
-    counts = [int(forced)] if forced else sorted({c for c in (8, 16, 32, 64) if c <= avail} or {avail})
+    counts = [int(forced)] if forced else sorted({c for c in (8, 16, 32, 64) if c <= avail} | {avail})
     torch.set_num_threads(counts[0])
     run(no_head, lens)  # warm-up (thread pool, allocator)
     probe = {}
@@ -127,11 +135,12 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
             ts.append(time.perf_counter() - t0)
         head = sorted(ts)[len(ts) // 2]
     est_step = lay * cfg.num_layers / L + head
-    return dict(value=B / est_step, unit="tokens/s", cores=cores, kind="port",
-                sample=f"torch-eager fp32 oracle, {cfg.name} dims, the GPU step's own batch: {B} requests, contexts mean "
+    return dict(value=B / est_step, unit="tokens/s", cores=cores, threads=cores, host_cores=avail,
+                value_all_host_cores=B / (probe[avail] * cfg.num_layers / L + head) if avail in probe else None, kind="port",
+                sample=f"torch-eager oracle (bf16-rounded weights, fp32 math), {cfg.name} dims, the GPU step's own batch: {B} requests, contexts mean "
                        f"{sum(lens) / B:.0f} through a page table; {L} of {cfg.num_layers} decoder layers timed "
                        f"({lay * 1e3:.0f} ms, median of {rounds}) x {cfg.num_layers // L} + embedding / final norm / LM head "
-                       f"({head * 1e3:.0f} ms): {est_step * 1e3:.0f} ms/step; threads tried (s per layer): "
+                       f"({head * 1e3:.0f} ms): {est_step * 1e3:.0f} ms/step; host has {avail} cores (sched_getaffinity), `cores` = the thread count used = the fastest of those tried (s per layer): "
                        + ", ".join(f"{c}: {t:.2f}" for c, t in probe.items()))
 
 
@@ -391,13 +400,14 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
                                      be.max_bs, be.capacity, be.scale, slot_run=be.slot_run)
     for _ in range(3):
         launch()
-    # Two measurements of one layer's launch (attention kernel + merge kernel), both with HIP events on the launch stream:
-    #  * busy stream (`us_per_launch`, what `achieved` uses): 30 launches queued back to back with an event after each, the
-    #    median distance between consecutive events -- how the launch runs inside the decode step, where the stream never
-    #    idles (rocprofv3 of the timed steps: 173.6 + 6.3 us per layer in round 5, profiles/r05_bench_timed_steps_*.txt;
-    #    this figure is within ~2 % of it);
-    #  * idle stream (`us_per_launch_idle_stream`): one synchronised event pair per launch, the method of rounds 1-4 -- it adds
-    #    the host-to-idle-GPU launch latency to every sample (5-8 % above the kernel trace, box dependent).
+    # One layer's launch = attention kernel + merge kernel.  Three HIP-event readings on the launch stream:
+    #  * `us_per_launch` (what `achieved` / `frac` use): ONE event pair around 40 launches queued back to back, divided by
+    #    40 -- covers both kernels and the gaps between them, the stream never idles (as inside the captured step); this is
+    #    the figure rocprofv3 --kernel-trace reproduces as (attention + merge) average duration (+ ~0.3 us of gaps);
+    #  * `us_per_launch_event_gap_median` (round 5's headline, kept for comparison): an event after every launch, median
+    #    distance of consecutive events -- reads ~3 % LOW (an event's stamp is taken before the merge kernel has drained);
+    #  * `us_per_launch_idle_stream` (rounds 1-4): one synchronised event pair per launch -- adds the host-to-idle-GPU
+    #    launch latency to every sample (5-8 % high, box dependent).
     reps, tot = 30, 0.0
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -416,7 +426,19 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
         evs[i + 1].record()
     evs[-1].synchronize()
     gaps = sorted(x.elapsed_time(y) for x, y in zip(evs[3:-1], evs[4:]))  # the first three gaps = ramp of the queue
-    attn_us = gaps[len(gaps) // 2] * 1e3  # partial + merge kernels of one layer
+    attn_us_gap = gaps[len(gaps) // 2] * 1e3
+    pair_reps, pair = 40, []
+    for _ in range(3):
+        for _ in range(5):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(pair_reps):
+            launch()
+        e1.record()
+        e1.synchronize()
+        pair.append(e0.elapsed_time(e1) * 1e3 / pair_reps)
+    attn_us = sorted(pair)[1]  # partial + merge kernels of one layer, median of three runs of 40
     S = sum(lens_now)
     attn_bytes = S * 2 * hkv * D * it + 2 * B * hq * D * it + S * 4 + 2 * B * 4
     achieved = attn_bytes / attn_us / 1e3
@@ -439,6 +461,12 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
             barrier()
             small[str(sb)] = (time.perf_counter() - t1) * 1e3 / 10
 
+    # the same algorithmic-byte model per small batch: weights + KV of the first sb requests + their logits
+    small_frac = {}
+    for k_, ms_ in small.items():
+        sb = int(k_)
+        sb_bytes = engine.model.streamed_bytes_per_step() + (sum(lens_now[:sb]) + sb) * kv_tok + sb * mcfg.vocab_size * it
+        small_frac[k_] = round(sb_bytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
     shape = f"{model_name} tp{world} B{B} page{args.page_size} bench_contexts"
     traffic, traffic_src, traffic_ratio = pmc_traffic(attn_bytes, shape)
     prefill_roofline = None
@@ -466,11 +494,13 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
         },
         "ttft_p50_ms": ttft_p50,
         "small_batch_ms_per_step": small,
+        "small_batch_step_roofline_frac": small_frac,
         "roofline": {
-            "bound": "hbm", "kernel": "attn_decode_mfma_kernel (+merge), one layer", "achieved": achieved,
+            "bound": "hbm", "kernel": "attn_decode_mfma_kernel + attn_decode_merge_kernel, one layer (both kernels timed)", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "traffic_source": traffic_src, "traffic_over_algorithmic": traffic_ratio, "us_per_launch": attn_us,
-            "us_per_launch_idle_stream": attn_us_idle, "timing": "median distance of consecutive HIP events over 30 launches queued back to back (busy stream, as inside the step); idle_stream = one synchronised event pair per launch (rounds 1-4)",
+            "us_per_launch_event_gap_median": attn_us_gap, "us_per_launch_idle_stream": attn_us_idle,
+            "timing": "us_per_launch = one HIP-event pair around 40 launches (attention + merge each) queued back to back / 40, median of 3: covers both kernels; event_gap_median = round 5's method (reads ~3 % low); idle_stream = one synchronised pair per launch (rounds 1-4, reads 5-8 % high)",
             "algorithmic_bytes": attn_bytes, "launch_shape": shape,
         },
         "prefill_roofline": prefill_roofline,
@@ -480,6 +510,7 @@ def run_workload(args, model_name: str, rank: int, local_rank: int, world: int, 
             "roofline_tokens_per_s": B * HBM_PEAK_GBPS * 1e9 / step_bytes,
         },
     }
+    result["_lens_now"] = list(lens_now)  # for the cpu_baseline leg (the GPU step's own contexts); popped before printing
     if collectives is not None:
         result["collectives"] = collectives
     # projection GEMMs at the full batch: weight bytes over the search's back-to-back times (what the kernels sustain on
@@ -636,9 +667,10 @@ def main() -> None:
                 result["e2e_offline"][name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(mcfg, contexts)
+            result["cpu_baseline"] = cpu_baseline(mcfg, result.pop("_lens_now", contexts))
         except Exception as e:  # never lose the GPU numbers to a host-side problem
             result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    result.pop("_lens_now", None)
     if rank == 0:
         # the LAST object of the line (a reader that keeps only the tail of stdout still sees the headline numbers)
         e2e = result.get("e2e_offline", {})

@@ -607,15 +607,20 @@ __device__ __forceinline__ int vimg_off(int tok, int byte_in_row) {
   return tok * 256 + (byte_in_row ^ ((tok & 3) << 6) ^ (((tok >> 2) & 1) << 5));
 }
 
+// K image (kLines): [16 tokens][256 B], the row's sixteen 16-byte pieces XORed by the token: the 16 lanes of one ds_read_b128
+// pass (one piece index, tokens 0..15) and of one ds_write_b128 pass (one token, pieces 0..15) both cover all 64 banks
+__device__ __forceinline__ int kimg_off(int tok, int piece) { return tok * 256 + (((piece ^ tok) & 15) << 4); }
+
 // kStages: register sets of the request ring; kMfmaWaves: waves per workgroup (8 = the kv heads of one slot at
 // hv = 8); kMinW: waves per SIMD the register budget is held to
 // kLoadsOnly (diagnosis, variant 92): the same requests and waits with the products left out -- what the request
 // pattern alone costs
 template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false, bool kTrace = false,
-          bool kCombine = false, bool kPrefetch = true>
+          bool kCombine = false, bool kPrefetch = true, bool kLines = true>
 __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kernel(const DecodeParams p) {
   constexpr int D = 128;
-  __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * 4096];
+  // per wave: the V image (4 KB) and, with kLines, the K image (4 KB) behind it
+  __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * (kLines ? 8192 : 4096)];
   unsigned long long stamp[14];  // kTrace (variant 93) only
   int n_stamp = 0;
   auto mark = [&]() {
@@ -640,10 +645,16 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
   const int4* items = reinterpret_cast<const int4*>(p.plan + plan_off_items(p.max_bs, p.capacity));
   const int item_begin = sgpr(slot_first[slot]);
   const int item_end = sgpr(slot_first[slot + 1]);
-  dlds_char* img = (dlds_char*)lds + wv * 4096;
-  int wr_off[4], rd_off[8];
+  dlds_char* img = (dlds_char*)lds + wv * (kLines ? 8192 : 4096);
+  // kLines: request j of a tile covers token rows 4 j + qd, lane piece `tok` (16 B) of the head's 256-B row -- whole 128-B
+  // lines per request, which is what lets the nt policy pay (see the banner above the kernel)
+  int wr_off[4], rd_off[8], kwr_off[4], krd_off[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) wr_off[kk] = vimg_off(tok, kk * 64 + qd * 16);
+  for (int kk = 0; kk < 4; ++kk) {
+    wr_off[kk] = kLines ? vimg_off(4 * kk + qd, tok * 16) : vimg_off(tok, kk * 64 + qd * 16);
+    kwr_off[kk] = 4096 + kimg_off(4 * kk + qd, tok);
+    krd_off[kk] = 4096 + kimg_off(tok, 4 * kk + qd);
+  }
 #pragma unroll
   for (int db = 0; db < 8; ++db) rd_off[db] = vimg_off(4 * qd + (tok >> 2), db * 32 + (tok & 3) * 8);
 
@@ -694,8 +705,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
       }
     }
     // byte offset of (token row tok, kv head, quarter) from the tile's first token row; step kk adds 64 B
-    const uint32_t voff = (uint32_t)(((int64_t)tok * p.kv_stride_tok + (int64_t)kvh * p.kv_stride_head + qd * 8) * 2);
-    const uint32_t voff0 = (uint32_t)(((int64_t)kvh * p.kv_stride_head + qd * 8) * 2);
+    // kLines: (token row qd of a group of four, piece tok); request kk adds four token rows
+    const uint32_t voff = kLines ? (uint32_t)(((int64_t)qd * p.kv_stride_tok + (int64_t)kvh * p.kv_stride_head + tok * 8) * 2)
+                                 : (uint32_t)(((int64_t)tok * p.kv_stride_tok + (int64_t)kvh * p.kv_stride_head + qd * 8) * 2);
+    const uint32_t voff0 = (uint32_t)(((int64_t)kvh * p.kv_stride_head + (kLines ? tok : qd) * 8) * 2);
+    const int row4 = sgpr((int)(p.kv_stride_tok * 8));  // bytes of four token rows (kLines)
 
     float m = kNegBig, l = 0.f;
     f32x4 o[8];
@@ -714,11 +728,21 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
           const_cast<char*>(reinterpret_cast<const char*>(p.k) + tile_bytes), (short)0, records, 0x00020000);
       const __amdgpu_buffer_rsrc_t vd = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(reinterpret_cast<const char*>(p.v) + tile_bytes), (short)0, records, 0x00020000);
-      const int vo = (int)(t0 + ti * 16 + tok < t1 ? voff : voff0);
+      if constexpr (kLines) {
+        const int left = t1 - (t0 + ti * 16) - qd;  // token 4 kk + qd of the tile is valid iff 4 kk < left
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        t.k[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, vo + kk * 64, 0, 0));
-        t.v[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, vo + kk * 64, 0, 0));
+        for (int kk = 0; kk < 4; ++kk) {
+          const int vo = 4 * kk < left ? (int)voff + kk * row4 : (int)voff0;
+          t.k[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, vo, 0, 2));
+          t.v[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, vo, 0, 2));
+        }
+      } else {
+        const int vo = (int)(t0 + ti * 16 + tok < t1 ? voff : voff0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          t.k[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, vo + kk * 64, 0, 0));
+          t.v[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, vo + kk * 64, 0, 0));
+        }
       }
     };
     auto compute = [&](const Tile& t, int tb) {
@@ -730,8 +754,18 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<__attribute__((address_space(3))) V4*>(img + wr_off[kk]) = t.v[kk];
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (kLines) {  // K rows -> the wave's K image, back in A-operand layout (token = lane & 15, dims 32 kk + 8 qd ..)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) s = mfma_k32<T>(t.k[kk], qf[kk], s);
+        for (int kk = 0; kk < 4; ++kk) *reinterpret_cast<__attribute__((address_space(3))) V4*>(img + kwr_off[kk]) = t.k[kk];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const V4 kf = *reinterpret_cast<__attribute__((address_space(3))) V4*>(img + krd_off[kk]);
+          s = mfma_k32<T>(kf, qf[kk], s);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s = mfma_k32<T>(t.k[kk], qf[kk], s);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)  // only the piece's last tile can be partial; four selects are cheaper than a second body
         if (tb + 4 * qd + i >= t1) s[i] = -INFINITY;
@@ -1058,7 +1092,7 @@ static int mfma_variant(int G) {
   const int c = decode_impl();
   if (c == 72) return 22;  // variant 22 with the in-kernel combine
   if (c == 71) return G <= 2 ? 32 : 22;  // the default variant, merge kernel forced
-  if (c >= 10 && c < 92) return c;
+  if (c >= 10 && c < 60) return c;
   return G <= 2 && c < 92 ? 32 : 22;
 }
 
@@ -1073,15 +1107,23 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
   // TP-shard shapes it LOSES 3-6 us per layer (14B TP4 49.1 vs 45.8 us, 70B TP8 35.4 vs 29.6, Qwen3-0.6B 174.3 vs 171.8:
   // the combiner's dependent sc1 round trips at the very end of a short kernel; profiles/r04_decode_ab_with_combine_as_impl0.txt, r04_decode_ab_final.txt) and 8 us at
   // B = 32.  Select code 71 = the default variant by its number (A/B partner of 72).
+  // Request shape.  Round 6 (tools/kv_stream_probe.hip, profiles/r06a_kv_stream_probe.txt): whole-line requests (4 token rows x
+  // 256 B) under the nt policy stream the paged pool at 6.8 TB/s where round 5's 16 rows x 64 B reach 5.9 (and LOSE with nt:
+  // nt lines bypass the L1, so the second 64-B half of a line is fetched again).  The price is K's trip through the wave's
+  // LDS image; it pays where the stream is long -- token rows of >= 1 KB (>= 4 local kv heads): 14B TP1 171.7 -> 153.6 us,
+  // Qwen3-0.6B 165.6 -> 145.1 -- and is neutral to -3 % on the short TP-shard launches (profiles/r06b_decode_ab.txt), which keep
+  // the direct-to-operand shape.  Select 60 / 61 force the round-5 / the whole-line shape (A/B; same bits either way).
+  const bool lines = decode_impl() == 61 || (decode_impl() != 60 && p.kv_stride_tok * 2 >= 1024);
   const bool combine = decode_impl() == 72 && p.hv <= kTicketHeads &&
                        (int64_t)capacity * p.hq * 128 * (int64_t)sizeof(float) < (1ll << 31);
 #define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, ...)                                                    \
   attn_decode_mfma_kernel<T, STAGES, WAVES, MINW, __VA_ARGS__>                                        \
       <<<dim3((unsigned)((waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, s>>>(p)
-#define MSGL_MFMA_VARIANT(STAGES, WAVES, MINW)                               \
-  do {                                                                       \
-    if (combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true);  \
-    else MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false);         \
+#define MSGL_MFMA_VARIANT(STAGES, WAVES, MINW)                                              \
+  do {                                                                                      \
+    if (!lines) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false, true, false);    \
+    else if (combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true);            \
+    else MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false);                        \
   } while (0)
   switch (decode_impl() >= 92 ? decode_impl() : mfma_variant(G)) {
     case 22: MSGL_MFMA_VARIANT(2, 8, 2); break;
@@ -1145,10 +1187,10 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 71 || impl == 72 || impl == 92 || impl == 93 || impl == 94,
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 71 || impl == 72 || impl == 92 || impl == 93 || impl == 94 || impl == 60 || impl == 61,
                "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
                "w waves per SIMD and s ring stages, 71 / 72 = the default variant with the merge kernel forced / with the "
-               "in-kernel combine forced)", impl);
+               "in-kernel combine forced, 60 / 61 = the default variant with round 5's 16-row x 64-B requests / with whole-line nt requests forced)", impl);
   g_decode_impl = impl;
   return MSGL_OK;
 }

@@ -92,6 +92,15 @@ def test_decode_matches_oracle_groups(ops, dev, hq, hkv, page_size):
         out, plan = run_decode(ops, dev, case, slot_run=slot_run)
         assert torch.isfinite(out.float()).all()
         torch.testing.assert_close(out.double(), ref, **TOL)
+        if slot_run >= 16:  # both request shapes of the matrix-core kernel, whatever the default picks for this row width
+            try:
+                outs = []
+                for code in (60, 61):
+                    ops.attn_decode_select(code)
+                    outs.append(run_decode(ops, dev, case, slot_run=slot_run)[0])
+            finally:
+                ops.attn_decode_select(0)
+            assert torch.equal(outs[0], out) and torch.equal(outs[1], out)
 
 
 @pytest.mark.parametrize("page_size,min_chunk", [(16, 16), (64, 64), (256, 64), (256, 256), (48, 32)])
@@ -137,6 +146,11 @@ def test_decode_long_pieces_through_the_request_ring(ops, dev, hq, hkv, dtype):
         ops.attn_decode_select(1)
         out_s, _ = run_decode(ops, dev, case, slot_run=256)
         torch.testing.assert_close(out_s.double(), ref, **TOL)
+        # round 6: whole-line nt requests with K transposed through LDS (default) vs round 5's 16-row x 64-B requests
+        # (select 60): the same products on the same operands in the same order => the same bits
+        ops.attn_decode_select(60)
+        out_r5, _ = run_decode(ops, dev, case, slot_run=256)
+        assert torch.equal(out, out_r5)
     finally:
         ops.attn_decode_select(0)
     err = (out.double() - ref).abs()

@@ -1,0 +1,60 @@
+#!/bin/bash
+# One parameterised entry for every GPU-box job of a round (replaces the per-call rNN_runK.sh scripts):
+#     gpurun --timeout 900 -- 'bash tools/gpu_job.sh <tag> <job> [<job> ...]'
+# Every job writes under gpurun_out/<tag>_* and prints a short digest; jobs are independent and each is bounded by its
+# own `timeout`.  Jobs:
+#   kv_probe          tools/kv_stream_probe.hip (request shape x policy x landing place for the paged K/V stream)
+#   decode_ab:<impls> tools/decode_ab.py on the six shapes with the given select codes (comma-separated)
+#   tests:<expr>      pytest -m gpu -k <expr>          tests_all   the whole GPU suite
+#   bench             the driver's bench command       bench_fast  the same without e2e / cpu baseline / prefill roofline
+#   trace_step        rocprofv3 kernel trace of the timed steps -> <tag>_bench_timed_steps_kernel_breakdown.txt
+#   rank_shard        bench.py --rank-shard on the five TP configurations
+#   smoke             __graft_entry__.smoke()
+#   py:<script args>  python tools/<script args>
+TAG=$1; shift
+R=$(pwd)
+mkdir -p gpurun_out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for JOB in "$@"; do
+  NAME=${JOB%%:*}; ARG=${JOB#*:}; [ "$ARG" == "$JOB" ] && ARG=""
+  echo "=== $TAG $JOB"
+  case $NAME in
+    kv_probe)
+      mkdir -p tools/build
+      [ -x tools/build/kv_stream_probe ] || hipcc -O3 --offload-arch=gfx950 tools/kv_stream_probe.hip -o tools/build/kv_stream_probe
+      timeout 300 tools/build/kv_stream_probe ${ARG:-3} > gpurun_out/${TAG}_kv_stream_probe.txt 2>&1; cat gpurun_out/${TAG}_kv_stream_probe.txt | cut -c1-200 ;;
+    decode_ab)
+      ( time timeout 600 python tools/decode_ab.py --impls ${ARG:-1,0,72} --shape 14b,14b_tp4,32b_tp4,70b_tp8,0.6b,14b_b32 --out gpurun_out/${TAG}_decode_ab.json ) > gpurun_out/${TAG}_decode_ab.txt 2>&1
+      grep -v "^$" gpurun_out/${TAG}_decode_ab.txt | tail -40 | cut -c1-200 ;;
+    tests)
+      ( time timeout 1500 python -m pytest tests -m gpu -q -x -k "$ARG" ) > gpurun_out/${TAG}_pytest_k.log 2>&1; tail -15 gpurun_out/${TAG}_pytest_k.log | cut -c1-300 ;;
+    tests_all)
+      ( time timeout 1700 python -m pytest tests -m gpu -q -x ) > gpurun_out/${TAG}_pytest.log 2>&1; tail -12 gpurun_out/${TAG}_pytest.log | cut -c1-300 ;;
+    bench|bench_fast)
+      EXTRA=""; [ $NAME == bench_fast ] && EXTRA="--no-e2e --no-cpu-baseline --no-prefill-roofline"
+      ( time timeout 900 python bench.py --steps 20 --warmup 5 $EXTRA $ARG ) > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+      tail -3 gpurun_out/${TAG}_bench.err | cut -c1-300
+      python - <<PY
+import json
+try:
+    d = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+    print(json.dumps(d.get("summary", {k: d[k] for k in ("value", "ms_per_step")})))
+    print(json.dumps(d["roofline"])[:900])
+    for r in d.get("gemm_tune", {}).get("refined_in_graph", []):
+        print(r["name"], r.get("chosen"), json.dumps(r.get("tried", r.get("ms", {})))[:400])
+except Exception as e:
+    print("bench line unreadable:", e)
+PY
+      ;;
+    trace_step) bash tools/trace_step.sh $TAG 2>&1 | tail -30 ;;
+    rank_shard)
+      MS=${ARG:-17.5}
+      for cfg in "qwen3-14b 4" "qwen3-32b 4" "qwen3-14b 2" "qwen3-14b 8" "llama-3.1-70b 8"; do set -- $cfg
+        timeout 240 python bench.py --model $1 --rank-shard $2 --tp1-ms $MS --steps 20 --warmup 5 2>gpurun_out/${TAG}_rank_shard_$1_tp$2.err | tail -1 > gpurun_out/${TAG}_rank_shard_$1_tp$2.json
+        python -c "import json; d=json.loads(open('gpurun_out/${TAG}_rank_shard_$1_tp$2.json').read()); print('$1 tp$2', round(d['ms_per_step'],3), 'ms')" 2>&1 | tail -1
+      done ;;
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    py) ( time timeout 900 python tools/$ARG ) 2>&1 | tail -40 | cut -c1-300 ;;
+    *) echo "unknown job $JOB" ;;
+  esac
+done
