@@ -616,8 +616,9 @@ __device__ __forceinline__ int kimg_off(int tok, int piece) { return tok * 256 +
 // kLoadsOnly (diagnosis, variant 92): the same requests and waits with the products left out -- what the request
 // pattern alone costs
 template <typename T, int kStages, int kMfmaWaves, int kMinW, bool kLoadsOnly = false, bool kTrace = false,
-          bool kCombine = false, bool kPrefetch = true, bool kLines = true>
+          bool kCombine = false, bool kPrefetch = true, bool kLines = true, bool kRun = true>
 __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kernel(const DecodeParams p) {
+  static_assert(kRun || kLines, "token-granular tables are gathered by whole-line requests only");
   constexpr int D = 128;
   // per wave: the V image (4 KB) and, with kLines, the K image (4 KB) behind it
   __shared__ __attribute__((aligned(16))) char lds[kMfmaWaves * (kLines ? 8192 : 4096)];
@@ -648,11 +649,14 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
   dlds_char* img = (dlds_char*)lds + wv * (kLines ? 8192 : 4096);
   // kLines: request j of a tile covers token rows 4 j + qd, lane piece `tok` (16 B) of the head's 256-B row -- whole 128-B
   // lines per request, which is what lets the nt policy pay (see the banner above the kernel)
+  // !kRun (token-granular page tables, round 6): lane group qd owns the tile's tokens 4 qd .. 4 qd + 3 -- ONE 16-byte table
+  // read per tile gives it their four pool slots -- and request kk fetches token 4 qd + kk's row by a per-lane address
   int wr_off[4], rd_off[8], kwr_off[4], krd_off[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    wr_off[kk] = kLines ? vimg_off(4 * kk + qd, tok * 16) : vimg_off(tok, kk * 64 + qd * 16);
-    kwr_off[kk] = 4096 + kimg_off(4 * kk + qd, tok);
+    const int wtok = kRun ? 4 * kk + qd : 4 * qd + kk;  // token of the tile this lane's request kk carries (kLines)
+    wr_off[kk] = kLines ? vimg_off(wtok, tok * 16) : vimg_off(tok, kk * 64 + qd * 16);
+    kwr_off[kk] = 4096 + kimg_off(wtok, tok);
     krd_off[kk] = 4096 + kimg_off(tok, 4 * kk + qd);
   }
 #pragma unroll
@@ -669,9 +673,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
   int4 it = items[item_begin], it2 = items2[item_begin];
   int b = sgpr(it.x);
   int row = p.req_rows ? sgpr(p.req_rows[b]) : b;
-  int pre_sl[kStages];  // pool slots of the first kStages tiles of the piece about to start (valid from the second piece on)
+  using Slots = std::conditional_t<kRun, int, int4>;  // a tile's pool slots: its first one (runs of >= 16) / the lane group's four
+  Slots pre_sl[kStages];  // pool slots of the first kStages tiles of the piece about to start (valid from the second piece on)
 #pragma unroll
-  for (int st = 0; st < kStages; ++st) pre_sl[st] = 0;
+  for (int st = 0; st < kStages; ++st) pre_sl[st] = Slots{};
   for (int item = item_begin; item < item_end; ++item) {
     if constexpr (!kPrefetch) {  // select code 94 (diagnosis): the dependent chain of the earlier form, for same-process A/B
       it = items[item];
@@ -721,7 +726,38 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
     // re-read the tile's first token (finite data for the masked lanes).  A tile past the piece's end is requested
     // through a descriptor of ZERO records: the eight loads still issue and retire in order -- the compiler's vmcnt
     // bookkeeping stays exact, with no branch around the requests -- but touch no memory and return zeros.
-    auto load_tile = [&](int sl, Tile& t, int ti) {
+    // token-granular tables: the four slots of tile-local tokens 4 qd .. 4 qd + 3 of the tile at position tb of table row `pt`
+    // whose tokens end at `end`; a lane group past the end reads the tile's first four entries instead (entries at or beyond
+    // a request's length are never dereferenced; load_tile replaces those of a partial group by a valid token's slot)
+    auto table_slots = [&](const int* pt, int tb, int end) -> int4 {
+      int tq = tb + 4 * qd;
+      if (tq >= end) tq = tb;
+      return *reinterpret_cast<const int4*>(pt + tq);
+    };
+    const int* vpt = p.page_table + (int64_t)row * p.pt_stride;
+    const uint64_t lane_bytes = (uint64_t)(((int64_t)kvh * p.kv_stride_head + tok * 8) * 2);  // (kv head, piece) inside a token row
+    const uint32_t row_bytes = (uint32_t)(p.kv_stride_tok * 2);
+    auto load_tile = [&](Slots sl, Tile& t, int ti) {
+      if constexpr (!kRun) {
+        // the slots in `sl` are those of tile min(ti, lt).  A tile past the piece's end still issues its eight requests (the
+        // compiler's vmcnt bookkeeping stays exact, no branch around them) but every lane then asks for the SAME 16 bytes of
+        // a valid row: one L2 hit per request, no HBM traffic.
+        const int tbc = t0 + min(ti, ntiles - 1) * 16;
+        int tq = tbc + 4 * qd;
+        if (tq >= t1) tq = tbc;
+        const int s4[4] = {sl.x, tq + 1 < t1 ? sl.y : sl.x, tq + 2 < t1 ? sl.z : sl.x, tq + 3 < t1 ? sl.w : sl.x};
+        const bool dead = ti >= ntiles;
+        const int s0 = sgpr(sl.x);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const uint64_t off = (uint64_t)(uint32_t)(dead ? s0 : s4[kk]) * row_bytes + (dead ? 0ull : lane_bytes);
+          const char* ka = reinterpret_cast<const char*>(p.k) + off;
+          const char* va = reinterpret_cast<const char*>(p.v) + off;
+          t.k[kk] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(ka));
+          t.v[kk] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(va));
+        }
+        return;
+      } else {
       const int64_t tile_bytes = (int64_t)sl * p.kv_stride_tok * 2;
       const int records = sgpr(ti < ntiles ? -1 : 0);
       const __amdgpu_buffer_rsrc_t kd = __builtin_amdgcn_make_buffer_rsrc(
@@ -743,6 +779,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
           t.k[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(kd, vo + kk * 64, 0, 0));
           t.v[kk] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(vd, vo + kk * 64, 0, 0));
         }
+      }
       }
     };
     auto compute = [&](const Tile& t, int tb) {
@@ -800,28 +837,41 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
     // products), consume it.  Pool slots come through the scalar cache one tile ahead of their use.
     Tile ring[kStages];
     const int lt = ntiles - 1;
-    const bool have_pre = kPrefetch && item > item_begin;
+    // (token-granular tables at three waves per SIMD: no register room for the next piece's slots, they are read at its start)
+    constexpr bool kPreSlots = kPrefetch && (kRun || kMinW < 3);
+    const bool have_pre = kPreSlots && item > item_begin;
+    auto tile_slots = [&](int ti) -> Slots {  // of tile min(ti, lt) of this piece
+      if constexpr (kRun) return cpt[t0 + min(ti, lt) * 16];
+      else return table_slots(vpt, t0 + min(ti, lt) * 16, t1);
+    };
 #pragma unroll
     for (int st = 0; st < kStages - 1; ++st) {
-      load_tile(have_pre ? pre_sl[st] : cpt[t0 + min(st, lt) * 16], ring[st], st);
+      load_tile(have_pre ? pre_sl[st] : tile_slots(st), ring[st], st);
       MSGL_PIN_MEM();  // oldest tile first: the scheduler is otherwise free to request them in any order
     }
-    int sn = have_pre ? pre_sl[kStages - 1] : cpt[t0 + min(kStages - 1, lt) * 16];  // slot of the next tile to request
+    Slots sn = have_pre ? pre_sl[kStages - 1] : tile_slots(kStages - 1);  // slot(s) of the next tile to request
     // the next piece's row and first slots (its records were requested above; this wait overlaps the first tiles' flight)
     const int nb = sgpr(nit.x);
     const int nrow = p.req_rows ? sgpr(p.req_rows[nb]) : nb;
     {
       const CInt* ncpt = (const CInt*)(p.page_table + (int64_t)nrow * p.pt_stride);
       const int nt0 = sgpr(nit.y) * 16;
-      const int nlt = ((min(sgpr(nit2.x), sgpr(nit.z) * 16) - nt0 + 15) >> 4) - 1;
+      const int nt1 = min(sgpr(nit2.x), sgpr(nit.z) * 16);
+      const int nlt = ((nt1 - nt0 + 15) >> 4) - 1;
 #pragma unroll
-      for (int st = 0; st < kStages; ++st) pre_sl[st] = ncpt[nt0 + min(st, nlt) * 16];
+      for (int st = 0; st < kStages; ++st) {
+        if constexpr (kRun) pre_sl[st] = ncpt[nt0 + min(st, nlt) * 16];
+        else if constexpr (kPreSlots) pre_sl[st] = table_slots(p.page_table + (int64_t)nrow * p.pt_stride, nt0 + min(st, nlt) * 16, nt1);
+      }
     }
     for (int tix = 0; tix < ntiles; tix += kStages) {
 #pragma unroll
       for (int st = 0; st < kStages; ++st) {
         const int cur = tix + st;
-        const int raw = cpt[t0 + min(cur + kStages, lt) * 16];
+        // (token-granular tables: a vector load, requested BEFORE the tile's K/V so that waiting for it next round does not
+        // wait for them -- vmcnt retires in order)
+        const Slots raw = tile_slots(cur + kStages);
+        if constexpr (!kRun) MSGL_PIN_MEM();
         load_tile(sn, ring[(st + kStages - 1) % kStages], cur + kStages - 1);
         pin_tile(ring[st]);
         if constexpr (kTrace) {
@@ -830,7 +880,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, kMinW) void attn_decode_mfma_kerne
         if (cur < ntiles) compute(ring[st], t0 + cur * 16);
         MSGL_PIN_MEM();
         sn = raw;
-        asm volatile("" : "+s"(sn));
+        if constexpr (kRun) asm volatile("" : "+s"(sn));
       }
     }
 
@@ -1084,9 +1134,9 @@ static int decode_impl() {
   if (g_decode_impl < 0) g_decode_impl = getenv("MSGL_DECODE_IMPL") ? atoi(getenv("MSGL_DECODE_IMPL")) : 0;
   return g_decode_impl;
 }
-// matrix-core kernel variants: code = 10 * (waves per SIMD) + ring stages.  Default: two stages (a deeper ring measured
-// the same or slower: tools/decode_ab.py, profiles/r02d_decode_ab.txt) at the residency the plan is made for -- three
-// waves per SIMD where the streaming kernel also has three (G <= 2), two otherwise.  92 = variant 22 without the
+// matrix-core kernel variants: code = 10 * (waves per SIMD) + ring stages.  Two stages (deeper rings measured the same or
+// slower in rounds 2-3: profiles/r02d_decode_ab.txt; round 6 removed their instantiations) at the residency the plan is made
+// for -- three waves per SIMD where the streaming kernel also has three (G <= 2), two otherwise.  92 = variant 22 without the
 // products (diagnosis).
 static int mfma_variant(int G) {
   const int c = decode_impl();
@@ -1116,18 +1166,23 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
   const bool lines = decode_impl() == 61 || (decode_impl() != 60 && p.kv_stride_tok * 2 >= 1024);
   const bool combine = decode_impl() == 72 && p.hv <= kTicketHeads &&
                        (int64_t)capacity * p.hq * 128 * (int64_t)sizeof(float) < (1ll << 31);
+  // token-granular page tables (slot_run < 16; the reference's default page_size = 1, P/engine/config.py:25): round 6 gives
+  // them the matrix-core kernel too -- whole-line requests by per-lane addresses, one 16-byte table read per lane group and
+  // tile -- instead of the round-1 streaming kernel
+  const bool run = p.slot_run >= 16;
 #define MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, ...)                                                    \
   attn_decode_mfma_kernel<T, STAGES, WAVES, MINW, __VA_ARGS__>                                        \
       <<<dim3((unsigned)((waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), 0, s>>>(p)
-#define MSGL_MFMA_VARIANT(STAGES, WAVES, MINW)                                              \
-  do {                                                                                      \
-    if (!lines) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false, true, false);    \
-    else if (combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true);            \
-    else MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false);                        \
+#define MSGL_MFMA_VARIANT(STAGES, WAVES, MINW)                                                                 \
+  do {                                                                                                         \
+    if (!run && combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true, true, true, false);         \
+    else if (!run) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false, true, true, false);              \
+    else if (!lines && combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true, true, false);        \
+    else if (!lines) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false, true, false);                  \
+    else if (combine) MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, true);                               \
+    else MSGL_MFMA_LAUNCH(STAGES, WAVES, MINW, false, false, false);                                           \
   } while (0)
-  switch (decode_impl() >= 92 ? decode_impl() : mfma_variant(G)) {
-    case 22: MSGL_MFMA_VARIANT(2, 8, 2); break;
-    case 23: MSGL_MFMA_VARIANT(3, 8, 2); break;
+  switch (run && decode_impl() >= 92 ? decode_impl() : mfma_variant(G)) {
     case 32: MSGL_MFMA_VARIANT(2, 4, 3); break;
     case 92:  // variant 22 without the products
       if (combine) MSGL_MFMA_LAUNCH(2, 8, 2, true, false, true);
@@ -1140,7 +1195,7 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
       if (combine) MSGL_MFMA_LAUNCH(2, 8, 2, false, true, true);
       else MSGL_MFMA_LAUNCH(2, 8, 2, false, true, false);
       break;
-    default: MSGL_MFMA_VARIANT(4, 8, 2); break;
+    default: MSGL_MFMA_VARIANT(2, 8, 2); break;  // 22
   }
 #undef MSGL_MFMA_VARIANT
 #undef MSGL_MFMA_LAUNCH
@@ -1153,7 +1208,7 @@ static int launch_decode_mfma(const DecodeParams& p, int batch, int capacity, hi
 
 template <typename T, int G>
 static int launch_decode(const DecodeParams& p, int batch, int capacity, hipStream_t s) {
-  if (p.slot_run >= 16 && decode_impl() != 1) return launch_decode_mfma<T, G>(p, batch, capacity, s);
+  if (decode_impl() != 1) return launch_decode_mfma<T, G>(p, batch, capacity, s);
   return p.slot_run >= 16 ? launch_decode_run<T, G, true>(p, batch, capacity, s)
                           : launch_decode_run<T, G, false>(p, batch, capacity, s);
 }
@@ -1187,9 +1242,9 @@ static int heads_per_unit(int group) {
 using namespace msgl;
 
 extern "C" int msgl_attn_decode_select(int impl) {
-  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 23 || impl == 24 || impl == 32 || impl == 71 || impl == 72 || impl == 92 || impl == 93 || impl == 94 || impl == 60 || impl == 61,
-               "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 10 w + s = matrix-core kernel with "
-               "w waves per SIMD and s ring stages, 71 / 72 = the default variant with the merge kernel forced / with the "
+  MSGL_REQUIRE(impl == 0 || impl == 1 || impl == 22 || impl == 32 || impl == 71 || impl == 72 || impl == 92 || impl == 93 || impl == 94 || impl == 60 || impl == 61,
+               "attn_decode_select: impl %d (0 = default, 1 = streaming kernel only, 22 / 32 = matrix-core kernel with "
+               "2 / 3 waves per SIMD (a two-stage request ring), 71 / 72 = the default variant with the merge kernel forced / with the "
                "in-kernel combine forced, 60 / 61 = the default variant with round 5's 16-row x 64-B requests / with whole-line nt requests forced)", impl);
   g_decode_impl = impl;
   return MSGL_OK;

@@ -28,6 +28,8 @@ def main() -> None:
     ap.add_argument("--shape", default="14b")
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--scale", type=float, default=1.0, help="multiply every context length (marginal bandwidth)")
+    ap.add_argument("--page", type=int, default=256, help="page size of the pool (slot_run = page if >= 16 else 1: token-granular table)")
+    ap.add_argument("--alloc", default="shuffled", choices=["shuffled", "sequential"], help="pages handed out in shuffled / allocation order")
     ap.add_argument("--out", default="gpurun_out/decode_ab.json")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -36,7 +38,8 @@ def main() -> None:
     for shape in args.shape.split(","):
         B, hq, hkv = SHAPES[shape]
         lens = [max(1, int(n * args.scale)) for n in bench_lens(B)]
-        k, v, table, q = decode_case(B, hq, hkv, lens, 256, dev)
+        k, v, table, q = decode_case(B, hq, hkv, lens, args.page, dev, shuffle=args.alloc == "shuffled")
+        slot_run = args.page if args.page >= 16 else 1
         D, cap = 128, max(4096, 2 * B)
         ws = torch.empty(ops.attn_decode_workspace_bytes(cap, hq, D), dtype=torch.uint8, device=dev)
         seq = torch.tensor(lens, dtype=torch.int32, device=dev)
@@ -53,7 +56,7 @@ def main() -> None:
             for impl in impls:
                 ops.attn_decode_select(impl)
                 f = lambda: ops.attn_decode(out, q, k, v, table, None, seq, plans[impl], ws, B, B, cap, D ** -0.5,  # noqa: E731
-                                            slot_run=256)
+                                            slot_run=slot_run)
                 for _ in range(60 if rnd == 0 else 15):
                     f()
                 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.iters)]
@@ -72,7 +75,7 @@ def main() -> None:
             med = sorted(times[impl])[len(times[impl]) // 2]
             res[shape][impl] = dict(us=[round(t, 1) for t in times[impl]], median_us=med, GBps=bytes_ / med / 1e3,
                                     slots=int(plans[impl][3]), max_diff_vs_first=(outs[impl].float() - ref).abs().max().item())
-            print(f"{shape} impl {impl:>2}: {[round(t, 1) for t in times[impl]]} us  median {med:.1f}  {bytes_ / med / 1e3:.0f} GB/s  "
+            print(f"{shape} page {args.page} {args.alloc} impl {impl:>2}: {[round(t, 1) for t in times[impl]]} us  median {med:.1f}  {bytes_ / med / 1e3:.0f} GB/s  "
                   f"slots {int(plans[impl][3])}  maxdiff {res[shape][impl]['max_diff_vs_first']:.1e}", flush=True)
         del k, v, table, q, ws
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)

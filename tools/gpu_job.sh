@@ -23,9 +23,11 @@ for JOB in "$@"; do
       mkdir -p tools/build
       [ -x tools/build/kv_stream_probe ] || hipcc -O3 --offload-arch=gfx950 tools/kv_stream_probe.hip -o tools/build/kv_stream_probe
       timeout 300 tools/build/kv_stream_probe ${ARG:-3} > gpurun_out/${TAG}_kv_stream_probe.txt 2>&1; cat gpurun_out/${TAG}_kv_stream_probe.txt | cut -c1-200 ;;
-    decode_ab)
-      ( time timeout 600 python tools/decode_ab.py --impls ${ARG:-1,0,72} --shape 14b,14b_tp4,32b_tp4,70b_tp8,0.6b,14b_b32 --out gpurun_out/${TAG}_decode_ab.json ) > gpurun_out/${TAG}_decode_ab.txt 2>&1
-      grep -v "^$" gpurun_out/${TAG}_decode_ab.txt | tail -40 | cut -c1-200 ;;
+    decode_ab)  # decode_ab:<impls>[:<page>[:<alloc>]]
+      IFS=: read -r IMPLS PAGE ALLOC <<< "$ARG"
+      SUF=""; [ -n "$PAGE" ] && SUF="_page${PAGE}_${ALLOC:-shuffled}"
+      ( time timeout 600 python tools/decode_ab.py --impls ${IMPLS:-1,0,72} --page ${PAGE:-256} --alloc ${ALLOC:-shuffled} --shape 14b,14b_tp4,32b_tp4,70b_tp8,0.6b,14b_b32 --out gpurun_out/${TAG}_decode_ab$SUF.json ) > gpurun_out/${TAG}_decode_ab$SUF.txt 2>&1
+      grep -v "^$" gpurun_out/${TAG}_decode_ab$SUF.txt | tail -40 | cut -c1-200 ;;
     tests)
       ( time timeout 1500 python -m pytest tests -m gpu -q -x -k "$ARG" ) > gpurun_out/${TAG}_pytest_k.log 2>&1; tail -15 gpurun_out/${TAG}_pytest_k.log | cut -c1-300 ;;
     tests_all)

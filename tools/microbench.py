@@ -49,14 +49,14 @@ def bench_lens(n=256, seed=0):
     return out
 
 
-def decode_case(B, hq, hkv, lens, page_size, dev, dtype=torch.bfloat16, D=128):
+def decode_case(B, hq, hkv, lens, page_size, dev, dtype=torch.bfloat16, D=128, shuffle=True):
     max_seq = (max(lens) + 31) // 32 * 32
     pages_per_req = (max_seq + page_size - 1) // page_size
     n_pages = B * pages_per_req + 1
     slots = n_pages * page_size
     k = torch.randn((slots, hkv, D), device=dev, dtype=dtype)
     v = torch.randn((slots, hkv, D), device=dev, dtype=dtype)
-    perm = torch.randperm(n_pages - 1)
+    perm = torch.randperm(n_pages - 1) if shuffle else torch.arange(n_pages - 1)  # pages in shuffled / allocation order
     table = torch.zeros((B, max_seq), dtype=torch.int32)
     p = 0
     for b in range(B):
