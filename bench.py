@@ -108,7 +108,8 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
     # thread count: torch-eager on a many-core host is not monotone in threads (the per-request attention loop and the
     # M = 256 GEMMs want different counts; 64 threads measured 3.5x SLOWER per layer than 8 on one box): one layer at each
     # of a few counts, the fastest is the baseline's (and is what `cores` reports)
-    counts = [int(forced)] if forced else sorted({c for c in (8, 16, 32, 64) if c <= avail} | {avail})
+    # (all 256 cores of a GPU box took 287 s for ONE layer in round 6 -- oversubscribed per-request attention loop: never probed)
+    counts = [int(forced)] if forced else sorted({c for c in (8, 16, 32, 64) if c <= avail} or {avail})
     torch.set_num_threads(counts[0])
     run(no_head, lens)  # warm-up (thread pool, allocator)
     probe = {}
@@ -136,7 +137,7 @@ def cpu_baseline(cfg, contexts, rounds: int = 3):
         head = sorted(ts)[len(ts) // 2]
     est_step = lay * cfg.num_layers / L + head
     return dict(value=B / est_step, unit="tokens/s", cores=cores, threads=cores, host_cores=avail,
-                value_all_host_cores=B / (probe[avail] * cfg.num_layers / L + head) if avail in probe else None, kind="port",
+                kind="port",
                 sample=f"torch-eager oracle (bf16-rounded weights, fp32 math), {cfg.name} dims, the GPU step's own batch: {B} requests, contexts mean "
                        f"{sum(lens) / B:.0f} through a page table; {L} of {cfg.num_layers} decoder layers timed "
                        f"({lay * 1e3:.0f} ms, median of {rounds}) x {cfg.num_layers // L} + embedding / final norm / LM head "
@@ -651,6 +652,34 @@ def main() -> None:
                                           "stale": d.get("code_fingerprint") != fp}
         except Exception as e:
             result["reference_driven"] = {"error": f"{type(e).__name__}: {e}"}
+    # the ONLINE half of the metric (BASELINE config 4's protocol): the reference's Scheduler fed a synthetic Qwen-like trace at
+    # the reference's scale list through the plugin -- recorded by tools/trace_replay.py (it imports oracle/_ref, this file may
+    # not) and committed under profiles/; stale when the product sources have changed since
+    if world == 1:
+        fp = product_code_fingerprint()
+        replays = {}
+        for f in sorted((ROOT / "profiles").glob("r*_trace_replay_*.json")):
+            try:
+                d = json.loads(f.read_text())
+            except Exception:
+                continue
+            if "scales" in d and d.get("model"):
+                replays[d["model"]] = {"kind": "committed", "source": f"profiles/{f.name}", "cache": d.get("cache"), "tp": d.get("tp"),
+                                       "trace": d.get("trace"), "recorded_on_code": d.get("code_fingerprint"), "this_code": fp,
+                                       "stale": d.get("code_fingerprint") != fp,
+                                       "by_scale": {k: {"complete": v["complete"], "throughput_tok_s": v["throughput_tok_s"],
+                                                        "ttft_ms": {q: v["ttft_ms"][q] for q in ("p50", "p90", "p99")},
+                                                        "tpot_ms": {q: v["tpot_ms"][q] for q in ("p50", "p90", "p99")}}
+                                                    for k, v in d["scales"].items()}}
+        if replays:
+            result["online_trace_replay"] = replays
+        # what the GPU parity suite compared on its last committed run (tests/parity_stats.py -> profiles/r*_parity_summary.json)
+        par = sorted((ROOT / "profiles").glob("r*_parity_summary.json"))
+        if par:
+            try:
+                result["parity"] = dict(json.loads(par[-1].read_text()), kind="committed", source=f"profiles/{par[-1].name}")
+            except Exception as e:
+                result["parity"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_e2e:
         # the reference's own throughput definition (benchmark/offline/bench.py:32-38): sum(max_tokens) / wall of one
         # generate() over 256 requests, in/out 100..1024, prefill included, one untimed warm-up -- BASELINE configs 1, 2
@@ -665,6 +694,15 @@ def main() -> None:
                                                                  "ttft_p50_ms")}
             except Exception as e:
                 result["e2e_offline"][name] = {"error": f"{type(e).__name__}: {e}"}
+        # the reference's DEFAULT page size (P/engine/config.py:25: page_size = 1; its FlashInfer backend always sees token-granular
+        # tables, P/attention/fi.py:179-187): the same workload on a token-granular pool (round 6: the matrix-core decode kernel
+        # gathers token rows by per-lane addresses)
+        try:
+            r = offline_run(args.model, 256, 0.6, 1, os.environ.get("MSGL_GEMM_TUNE", "full"), device)
+            result["e2e_offline_page_size_1"] = {args.model: {k: r[k] for k in ("throughput_tok_s", "wall_s", "decode_steps", "ms_per_decode_step",
+                                                                               "prefill_tok_s", "ttft_p50_ms", "page_size")}}
+        except Exception as e:
+            result["e2e_offline_page_size_1"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(mcfg, result.pop("_lens_now", contexts))
@@ -681,6 +719,10 @@ def main() -> None:
             "small_batch_ms_per_step": result.get("small_batch_ms_per_step"),
             "ttft_p50_ms": result.get("ttft_p50_ms"),
             "e2e_offline_tok_s": {k: round(v["throughput_tok_s"]) for k, v in e2e.items() if "throughput_tok_s" in v},
+            "e2e_offline_page_size_1_tok_s": {k: round(v["throughput_tok_s"]) for k, v in result.get("e2e_offline_page_size_1", {}).items()
+                                              if isinstance(v, dict) and "throughput_tok_s" in v},
+            "small_batch_step_roofline_frac": result.get("small_batch_step_roofline_frac"),
+            "bit_identical_forwards_vs_reference_driven": (result.get("parity") or {}).get("bit_identical_forwards"),
             "prefill_attn_frac": (result.get("prefill_roofline") or {}).get("frac"),
             "reference_driven_ms": (result.get("reference_driven") or {}).get("decode_ms_per_step"),
             "reference_driven_stale": (result.get("reference_driven") or {}).get("stale"),

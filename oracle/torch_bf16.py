@@ -10,6 +10,10 @@ accumulation order) and attention is written out with torch matmuls, P rounded t
 flash-attention convention).  Nothing here comes from mini-sglang_amd: no kernel, no plan, no layout helper.
 
 tests/ compare   |ours - fp32 oracle|   with   |this - fp32 oracle|   on the same teacher-forced batches.
+
+Round 6: `linear="fp32acc"` replaces every F.linear by an fp32 matmul of the bf16 values rounded once to
+bf16 -- with CPU tensors that is a bf16 pipeline whose GEMMs owe nothing to hipBLASLt / rocBLAS (the floor is then independent
+of the device and of its libraries).
 """
 from __future__ import annotations
 
@@ -81,16 +85,21 @@ def _attention(q: torch.Tensor, k_pool: torch.Tensor, v_pool: torch.Tensor, tabl
     return out
 
 
+def _linear_fp32acc(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    return (x.float() @ w.float().t()).to(x.dtype)
+
+
 def forward(cfg: Any, w: Any, input_ids: torch.Tensor, positions: torch.Tensor, out_loc: torch.Tensor,
             k_pool: List[torch.Tensor], v_pool: List[torch.Tensor], page_table: torch.Tensor, req_rows: Sequence[int],
             k_lens: Sequence[int], q_lens: Sequence[int], is_prefill: bool,
-            hq: Optional[int] = None, hkv: Optional[int] = None) -> torch.Tensor:
+            hq: Optional[int] = None, hkv: Optional[int] = None, linear: str = "library") -> torch.Tensor:
     """Same contract as ref_model.forward, every tensor on the GPU; k_pool[l] / v_pool[l] [slots, Hkv, D] are updated in
     place at out_loc.  Returns logits [B, vocab] in the model dtype."""
     D = cfg.head_dim
     hq = hq or cfg.num_qo_heads
     hkv = hkv or cfg.num_kv_heads
     eps = cfg.rms_norm_eps
+    lin = F.linear if linear == "library" else _linear_fp32acc
     x = F.embedding(input_ids.long(), w.embed)
     residual = None
     for li, lw in enumerate(w.layers):
@@ -99,7 +108,7 @@ def forward(cfg: Any, w: Any, input_ids: torch.Tensor, positions: torch.Tensor, 
             x = _rmsnorm(x, lw["input_norm"], eps)
         else:
             x, residual = _add_rmsnorm(x, residual, lw["input_norm"], eps)
-        qkv = F.linear(x, lw["qkv"])
+        qkv = lin(x, lw["qkv"])
         q, k, v = qkv.split([hq * D, hkv * D, hkv * D], dim=-1)
         T = q.shape[0]
         if lw["q_norm"] is not None:
@@ -109,13 +118,13 @@ def forward(cfg: Any, w: Any, input_ids: torch.Tensor, positions: torch.Tensor, 
         k_pool[li][out_loc.long()] = k.view(T, hkv, D)
         v_pool[li][out_loc.long()] = v.reshape(T, hkv, D)
         o = _attention(q.view(T, hq, D), k_pool[li], v_pool[li], page_table, req_rows, k_lens, q_lens, D ** -0.5)
-        x = F.linear(o.view(T, hq * D), lw["o"])
+        x = lin(o.view(T, hq * D), lw["o"])
         x, residual = _add_rmsnorm(x, residual, lw["post_norm"], eps)
-        gu = F.linear(x, lw["gate_up"])
+        gu = lin(x, lw["gate_up"])
         half = gu.shape[-1] // 2
         y = (F.silu(gu[:, :half].float()) * gu[:, half:].float()).to(gu.dtype)
-        x = F.linear(y, lw["down"])
+        x = lin(y, lw["down"])
     x, _ = _add_rmsnorm(x, residual, w.final_norm, eps)
     if is_prefill:
         x = x[torch.tensor(q_lens, device=x.device).cumsum(0) - 1]
-    return F.linear(x, w.lm_head)
+    return lin(x, w.lm_head)

@@ -7,9 +7,58 @@ bound set from the measured distribution plus a margin, and state where 1e-3 is 
 """
 from __future__ import annotations
 
-from typing import Dict
+import json
+import os
+from pathlib import Path
+from typing import Any, Dict, List
 
 import torch
+
+# What the session compared, for the pytest terminal summary and gpurun_out/parity_summary.json (tests/conftest.py writes both;
+# bench.py surfaces the committed copy under profiles/ as `parity`, kind "committed").  Two kinds of record:
+#   bit_identical: label -> number of forwards whose logits matched BIT FOR BIT (reference-driven replays, rank pairs)
+#   logits:        label -> error distribution of ours, of the torch-bf16 floor on the GPU's library GEMMs, and of the
+#                  CPU floor (fp32-accumulating matmul on bf16-rounded inputs: independent of the device's libraries)
+RECORDS: List[Dict[str, Any]] = []
+
+
+def record(kind: str, label: str, **fields: Any) -> None:
+    RECORDS.append(dict(kind=kind, label=label, **fields))
+
+
+def _brief(st: Dict[str, float]) -> Dict[str, float]:
+    return {k: st[k] for k in ("n", "ref_std", "max_abs", "p99_abs", "mean_abs", "frac_gt_1e3")} if st else None
+
+
+def summary_lines() -> List[str]:
+    out = []
+    bit = [r for r in RECORDS if r["kind"] == "bit_identical"]
+    if bit:
+        out.append(f"bit-identical logits: {sum(r['forwards'] for r in bit)} forwards in {len(bit)} scenarios "
+                   f"(reference-driven through the plugin vs the repository's engine, rank vs rank)")
+        out += [f"    {r['forwards']:4d}  {r['label']}" for r in bit]
+    for r in (r for r in RECORDS if r["kind"] == "logits"):
+        f = lambda st: "n/a" if not st else (f"max {st['max_abs']:.2e} p99 {st['p99_abs']:.2e} mean {st['mean_abs']:.2e} "  # noqa: E731
+                                             f"frac>1e-3 {st['frac_gt_1e3']:.3f}")
+        out.append(f"logits vs the fp32 oracle [{r['label']}] (ref std {r['ours']['ref_std']:.2f}, n {r['ours']['n']})")
+        out.append(f"    ours                       {f(r['ours'])}  argmax {r.get('ours_agree')}/{r.get('total')}")
+        out.append(f"    torch-bf16 (GPU library)   {f(r.get('floor_gpu'))}  argmax {r.get('floor_gpu_agree')}/{r.get('total')}")
+        out.append(f"    bf16-rounded fp32-acc (CPU) {f(r.get('floor_cpu'))}  argmax {r.get('floor_cpu_agree')}/{r.get('total')}")
+    return out
+
+
+def write_summary(path: Path) -> None:
+    if not RECORDS:
+        return
+    bit = [r for r in RECORDS if r["kind"] == "bit_identical"]
+    path.parent.mkdir(parents=True, exist_ok=True)
+    path.write_text(json.dumps(dict(
+        bit_identical_forwards=sum(r["forwards"] for r in bit), bit_identical_scenarios=[dict(label=r["label"], forwards=r["forwards"]) for r in bit],
+        logits=[dict(label=r["label"], ours=_brief(r["ours"]), floor_gpu_library=_brief(r.get("floor_gpu")),
+                     floor_cpu_fp32acc=_brief(r.get("floor_cpu")), argmax=dict(ours=r.get("ours_agree"), floor_gpu=r.get("floor_gpu_agree"),
+                                                                               floor_cpu=r.get("floor_cpu_agree"), total=r.get("total")))
+                for r in RECORDS if r["kind"] == "logits"],
+        note="north_star's 1e-3 is below one bf16 ulp for |logit| > 0.25; frac_gt_1e3 shows where each bf16 pipeline sits"), indent=1))
 
 
 def bf16_ulp(x: torch.Tensor) -> torch.Tensor:
@@ -60,11 +109,18 @@ def floor_report(label: str, ours: Dict[str, float], floor: Dict[str, float], ou
 
 
 def assert_not_above_bf16_floor(label: str, ours: Dict[str, float], floor: Dict[str, float], ours_agree: int, floor_agree: int,
-                                total: int) -> None:
+                                total: int, floor_cpu: Dict[str, float] = None, floor_cpu_agree: int = None) -> None:
     """|ours - oracle| must be statistically no larger than |independent torch-bf16 forward - oracle| (oracle/torch_bf16.py):
     mean and p99 within 25 % of the floor's, the maximum (one sample of the tail) within 50 %, and the argmax of ours
     agrees with the oracle's at least as often as the floor's does (minus 1 % of the rows for ties broken the other way)."""
     print(floor_report(label, ours, floor, ours_agree, floor_agree, total))
+    record("logits", label, ours=ours, floor_gpu=floor, floor_cpu=floor_cpu, ours_agree=ours_agree, floor_gpu_agree=floor_agree,
+           floor_cpu_agree=floor_cpu_agree, total=total)
+    if floor_cpu:
+        # the floor that owes nothing to the device's GEMM libraries: exact-input fp32 accumulation, one rounding per op
+        print(f"    cpu-floor   {fmt(floor_cpu)}; argmax agreement {floor_cpu_agree}/{total}")
+        assert ours["mean_abs"] <= 1.35 * floor_cpu["mean_abs"] + 1e-7, label
+        assert ours["p99_abs"] <= 1.35 * floor_cpu["p99_abs"] + 1e-7, label
     assert ours["mean_abs"] <= 1.25 * floor["mean_abs"] + 1e-7, label
     assert ours["p99_abs"] <= 1.25 * floor["p99_abs"] + 1e-7, label
     assert ours["max_abs"] <= 1.5 * floor["max_abs"] + 1e-7, label

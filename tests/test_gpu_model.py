@@ -119,9 +119,23 @@ def test_prefill_batch_of_one_token_extensions_runs_eagerly_with_graphs_captured
     e1.shutdown()
     assert [r["phase"] for r in rec[:2]] == ["prefill", "prefill"] and rec[1]["q_lens"] == [1] and rec[1]["k_lens"] == [65]
     e2 = make_engine(dev, graphs=True)
-    ids2, _, _ = run(e2, ps, 5)  # unchunked
+    rec2 = []
+    ids2, _, _ = run(e2, ps, 5, record=rec2)  # unchunked
     e2.shutdown()
-    assert ids1 == ids2
+    # The one-token chunk goes through the DECODE kernel, the unchunked prompt's last token through the PREFILL kernel: two
+    # summation orders of the same attention, so the runs agree within the logit tolerance, not bit for bit, and the greedy
+    # continuation is the same until a near-tie (round 6: the matrix-core decode kernel now also serves this model's
+    # 4-token pages and flips one such tie that the streaming kernel happened not to).  Compared forward by forward up to the
+    # first divergence, which must BE a near-tie in both runs.
+    for a, b in zip(rec[1:], rec2):
+        la, lb = a["logits"][0], b["logits"][0]
+        assert (la - lb).abs().max().item() <= LOGIT_TOL
+        ia, ib = int(la.argmax()), int(lb.argmax())
+        if ia != ib:
+            assert abs(float(lb[ib] - lb[ia])) <= 2 * LOGIT_TOL and abs(float(la[ia] - la[ib])) <= 2 * LOGIT_TOL
+            break
+    else:
+        assert ids1 == ids2
 
 
 @pytest.mark.parametrize("name,page_size", [("tiny", 4), ("tiny-llama", 1)])
@@ -136,12 +150,14 @@ def test_teacher_forced_parity_vs_cpu_oracle(dev, name, page_size):
     slots = eng.kv_cache.pool.shape[2] * eng.kv_cache.pool.shape[3]
     kp = [torch.zeros((slots, cfg.num_kv_heads, cfg.head_dim), dtype=torch.bfloat16) for _ in range(cfg.num_layers)]
     vp = [torch.zeros_like(k) for k in kp]
-    agree = total = floor_agree = 0
-    stats, floor = {}, {}
-    # the independent bf16 forward (plain torch ops on the GPU, oracle/torch_bf16.py): where a bf16 pipeline sits
+    agree = total = floor_agree = cfloor_agree = 0
+    stats, floor, cfloor = {}, {}, {}
+    # the independent bf16 forward (plain torch ops on the GPU, oracle/torch_bf16.py): where a bf16 pipeline sits; and the same
+    # forward on the CPU with fp32-accumulating matmuls of the bf16 values (no device library in it)
     wd, table_d = torch_bf16.weights_to(w, dev), table.to(dev)
     kpd = [torch.zeros_like(k, device=dev) for k in kp]
     vpd = [torch.zeros_like(k) for k in kpd]
+    kpc, vpc = [torch.zeros_like(k) for k in kp], [torch.zeros_like(k) for k in kp]
     for r in rec:
         logits = ref_model.forward(cfg, w, r["input_ids"], r["positions"], r["out_loc"], kp, vp, table, r["rows"],
                                    r["k_lens"], r["q_lens"], r["phase"] == "prefill").float()[: r["size"]]
@@ -149,6 +165,10 @@ def test_teacher_forced_parity_vs_cpu_oracle(dev, name, page_size):
                                 r["rows"], r["k_lens"], r["q_lens"], r["phase"] == "prefill").float().cpu()[: r["size"]]
         floor = parity_stats.merge_stats(floor, parity_stats.logit_error_stats(tb, logits))
         floor_agree += int((tb.argmax(-1) == logits.argmax(-1)).sum())
+        tc = torch_bf16.forward(cfg, w, r["input_ids"], r["positions"], r["out_loc"], kpc, vpc, table, r["rows"], r["k_lens"],
+                                r["q_lens"], r["phase"] == "prefill", linear="fp32acc").float()[: r["size"]]
+        cfloor = parity_stats.merge_stats(cfloor, parity_stats.logit_error_stats(tc, logits))
+        cfloor_agree += int((tc.argmax(-1) == logits.argmax(-1)).sum())
         st = parity_stats.logit_error_stats(r["logits"], logits)
         stats = parity_stats.merge_stats(stats, st)
         assert st["max_abs"] <= LOGIT_TOL, parity_stats.fmt(st)
@@ -160,7 +180,8 @@ def test_teacher_forced_parity_vs_cpu_oracle(dev, name, page_size):
         total += same.numel()
     print(f"\n[teacher-forced {name} page {page_size}] {parity_stats.fmt(stats)}; argmax agreement {agree}/{total}")
     assert agree >= 0.9 * total and stats["p99_abs"] <= LOGIT_TOL / 2
-    parity_stats.assert_not_above_bf16_floor(f"{name}, {cfg.num_layers} layers", stats, floor, agree, floor_agree, total)
+    parity_stats.assert_not_above_bf16_floor(f"{name}, {cfg.num_layers} layers", stats, floor, agree, floor_agree, total,
+                                             floor_cpu=cfloor, floor_cpu_agree=cfloor_agree)
     # KV pool contents: every slot the run wrote agrees with the oracle's pool
     dev_k = eng.kv_cache.pool[0].cpu().view(cfg.num_layers, slots, cfg.num_kv_heads, cfg.head_dim)
     for li in range(cfg.num_layers):
@@ -223,11 +244,12 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
     kp = [torch.zeros((slots, m.num_kv_heads, m.head_dim), dtype=torch.bfloat16) for _ in range(m.num_layers)]
     vp = [torch.zeros_like(k) for k in kp]
     row = rec[0]["rows"][0]
-    sure_n = same_n = floor_same = 0
-    floor = {}
+    sure_n = same_n = floor_same = cfloor_same = 0
+    floor, cfloor = {}, {}
     wd, table_d = torch_bf16.weights_to(w, dev), table.to(dev)
     kpd = [torch.zeros_like(k, device=dev) for k in kp]
     vpd = [torch.zeros_like(k) for k in kpd]
+    kpc, vpc = [torch.zeros_like(k) for k in kp], [torch.zeros_like(k) for k in kp]
     for step, r in enumerate(rec):
         # KV block indices: the slots this forward writes are the table's entries for its positions
         assert torch.equal(r["out_loc"].long(), table[row, r["positions"].long()].long())
@@ -237,6 +259,10 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
                                 r["rows"], r["k_lens"], r["q_lens"], r["phase"] == "prefill").float().cpu()[: r["size"]]
         floor = parity_stats.merge_stats(floor, parity_stats.logit_error_stats(tb, logits))
         floor_same += int(tb.argmax(-1)[0]) == int(logits.argmax(-1)[0])
+        tc = torch_bf16.forward(m, w, r["input_ids"], r["positions"], r["out_loc"], kpc, vpc, table, r["rows"], r["k_lens"],
+                                r["q_lens"], r["phase"] == "prefill", linear="fp32acc").float()[: r["size"]]
+        cfloor = parity_stats.merge_stats(cfloor, parity_stats.logit_error_stats(tc, logits))
+        cfloor_same += int(tc.argmax(-1)[0]) == int(logits.argmax(-1)[0])
         st = parity_stats.logit_error_stats(r["logits"], logits)
         dist = parity_stats.merge_stats(dist, st)
         assert st["max_abs"] <= tol, (step, parity_stats.fmt(st))
@@ -251,7 +277,8 @@ def test_baseline_config0_qwen3_0p6b_single_prompt_greedy(dev, page_size, new_to
     print(f"\n[config 0, Qwen3-0.6B dims, page {page_size}] {parity_stats.fmt(dist)}; greedy ids equal at {same_n}/{len(rec)} "
           f"steps ({sure_n} with a sure oracle margin)")
     assert dist["p99_abs"] <= tol / 2 and dist["mean_ulp"] <= 8.0
-    parity_stats.assert_not_above_bf16_floor(f"Qwen3-0.6B dims, 28 layers, page {page_size}", dist, floor, same_n, floor_same, len(rec))
+    parity_stats.assert_not_above_bf16_floor(f"Qwen3-0.6B dims, 28 layers, page {page_size}", dist, floor, same_n, floor_same, len(rec),
+                                             floor_cpu=cfloor, floor_cpu_agree=cfloor_same)
     dev_k = eng.kv_cache.pool[0].cpu().view(m.num_layers, slots, m.num_kv_heads, m.head_dim)
     for li in (0, m.num_layers // 2, m.num_layers - 1):  # one bf16 ulp of a K element of magnitude 4 is 3e-2
         torch.testing.assert_close(dev_k[li][:-page_size].float(), kp[li][:-page_size].float(), atol=tol, rtol=tol)

@@ -31,8 +31,19 @@ import parity_stats
 import refdrive
 from refdrive_worker import logits_summary
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(refdrive.reference_root() is None, reason="no importable reference (oracle/_ref)")]
+pytestmark = [pytest.mark.gpu]
+
+
+@pytest.fixture(autouse=True)
+def _reference_must_travel():
+    """Round 6: on a GPU box a missing oracle/_ref FAILS these scenarios -- the strongest parity evidence of
+    the repository must not turn into silent skips (the build container creates it: __graft_entry__.build() -> oracle/build_ref.sh;
+    it is git-ignored but not gpurun-ignored, so it travels with the snapshot)."""
+    if refdrive.reference_root() is None:
+        if torch.cuda.is_available():
+            pytest.fail("oracle/_ref (the reference's own package, built by oracle/build_ref.sh) is absent on this GPU box: the "
+                        "reference-driven scenarios cannot run -- run __graft_entry__.build() where /root/reference exists")
+        pytest.skip("no importable reference (oracle/_ref) and no GPU")
 
 ROOT = Path(__file__).resolve().parent.parent
 ORACLE_TOL = 3e-2  # tiny dims (2 layers, logit std ~0.3): measured max 1.6e-2 in round 1; distribution printed
@@ -79,7 +90,8 @@ def replay(eng, rec):
     return [logits_summary(replay_forward(eng, f)) for f in rec["forwards"]]
 
 
-def assert_bit_identical(rec, mine):
+def assert_bit_identical(rec, mine, label=None):
+    label = label or os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
     bad = []
     for i, (f, s) in enumerate(zip(rec["forwards"], mine)):
         r = f["summary"]
@@ -89,6 +101,7 @@ def assert_bit_identical(rec, mine):
             d = (r["top2"] - s["top2"]).abs().max().item() if r["top2"].shape == s["top2"].shape else float("nan")
             bad.append((i, f["phase"], f["size"], f["padded_size"], f["graph"], d))
     assert not bad, f"{len(bad)} of {len(mine)} forwards differ between reference-driven and repo engine: {bad[:8]}"
+    parity_stats.record("bit_identical", f"reference LLM through the plugin == repo engine: {label}", forwards=len(mine))
 
 
 def greedy(n_tokens):
@@ -292,6 +305,7 @@ def test_reference_driven_tp2_through_the_plugin_two_ranks_on_one_gpu(dev, model
         assert rep["comm_error"] == 0
         assert all(rep["bit_identical"]), [i for i, ok in enumerate(rep["bit_identical"]) if not ok]
     worst = max(r0["repo_replay"]["max_abs_vs_tp1"])
+    parity_stats.record("bit_identical", "reference tp=2 through the plugin: rank 0 == rank 1 (two ranks on one GPU)", forwards=len(r0["forwards"]))
     print(f"\n[refdrive tp2, two ranks on one GPU] {len(r0['forwards'])} forwards, ranks bit-identical, == repo tp2 engine bit for bit; "
           f"max |logit| difference to the tp1 engine {worst:.2e}")
     assert worst <= 2e-2

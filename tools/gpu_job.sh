@@ -9,6 +9,7 @@
 #   bench             the driver's bench command       bench_fast  the same without e2e / cpu baseline / prefill roofline
 #   trace_step        rocprofv3 kernel trace of the timed steps -> <tag>_bench_timed_steps_kernel_breakdown.txt
 #   rank_shard        bench.py --rank-shard on the five TP configurations
+#   trace_replay:<model>[:<requests>]  tools/trace_replay.py at the reference's six scales, --cache naive
 #   smoke             __graft_entry__.smoke()
 #   py:<script args>  python tools/<script args>
 TAG=$1; shift
@@ -55,6 +56,9 @@ PY
         timeout 240 python bench.py --model $1 --rank-shard $2 --tp1-ms $MS --steps 20 --warmup 5 2>gpurun_out/${TAG}_rank_shard_$1_tp$2.err | tail -1 > gpurun_out/${TAG}_rank_shard_$1_tp$2.json
         python -c "import json; d=json.loads(open('gpurun_out/${TAG}_rank_shard_$1_tp$2.json').read()); print('$1 tp$2', round(d['ms_per_step'],3), 'ms')" 2>&1 | tail -1
       done ;;
+    trace_replay)
+      IFS=: read -r MODEL NREQ <<< "$ARG"
+      ( time timeout 1700 python tools/trace_replay.py --model ${MODEL:-qwen3-14b} --requests ${NREQ:-300} --out gpurun_out/${TAG}_trace_replay_${MODEL:-qwen3-14b}_tp1.json ) 2>&1 | tail -12 | cut -c1-400 ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     py) ( time timeout 900 python tools/$ARG ) 2>&1 | tail -40 | cut -c1-300 ;;
     *) echo "unknown job $JOB" ;;
