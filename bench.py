@@ -232,26 +232,110 @@ def self_launch_command(gpus: int, argv):
     return cmd, env
 
 
+LAST_PREFLIGHT: dict = {}  # what check_collectives last measured (for the line a failed multi-GPU run still prints)
+
+
+def _known_answers(f_all_reduce, f_all_gather, rank: int, world: int, device, numel: int) -> list:
+    """The reference's own known answers (tests/kernel/test_comm.py:96-149) through one path at one message size: ones
+    reduced four times -> world^4; rank-valued with rank 0 arriving 0.2 s late -> n(n-1)/2; half zeros / half ones ->
+    [0, world]; all-gather of rank-valued chunks -> 0,0,..,1,1,..  Returns the list of failed checks (empty = pass)."""
+    bad = []
+    sync = (lambda: torch.cuda.synchronize(device)) if torch.device(device).type == "cuda" else (lambda: None)
+    x = torch.ones(numel, dtype=torch.bfloat16, device=device)
+    for _ in range(4):
+        f_all_reduce(x)
+    sync()
+    if not bool((x == float(world ** 4)).all()):
+        bad.append(f"ones x4 -> {x[0].item()} .. {x[-1].item()}, want {world ** 4}")
+    x = torch.full((numel,), float(rank), dtype=torch.bfloat16, device=device)
+    if rank == 0:  # a lagging rank: the others must wait for it, not sum stale data
+        sync()
+        time.sleep(0.2)
+    f_all_reduce(x)
+    sync()
+    if not bool((x == float(world * (world - 1) // 2)).all()):
+        bad.append(f"rank-valued with a lagging rank -> {x[0].item()}, want {world * (world - 1) // 2}")
+    x = torch.cat([torch.zeros(numel // 2, dtype=torch.bfloat16, device=device), torch.ones(numel - numel // 2, dtype=torch.bfloat16, device=device)])
+    f_all_reduce(x)
+    sync()
+    if not (bool((x[: numel // 2] == 0).all()) and bool((x[numel // 2:] == float(world)).all())):
+        bad.append("half zeros / half ones: wrong halves")
+    n = max(8, (numel // world) // 8 * 8)
+    src = torch.full((n,), float(rank), dtype=torch.bfloat16, device=device)
+    dst = torch.empty((n * world,), dtype=torch.bfloat16, device=device)
+    f_all_gather(dst, src)
+    sync()
+    if not torch.equal(dst, torch.arange(world, dtype=torch.bfloat16, device=device).repeat_interleave(n)):
+        bad.append("all-gather: wrong contents")
+    return bad
+
+
 def check_collectives(comm, rank: int, world: int, device) -> dict:
-    """Known answers on the links the run is about to use, and what the libraries themselves report: rank-valued data ->
-    n(n+1)/2 through RCCL directly (whatever the hybrid dispatch would pick for the size) and `ncclCommCount` as
-    `rccl_ranks_seen`; the peer-to-peer kernels were checked the same way by init_pynccl (kernel.P2PCommunicator.
-    self_test) -- a failure there leaves comm.p2p None and RCCL carries every message."""
+    """PREFLIGHT on the links the run is about to use, printed to stderr by rank 0 BEFORE the workload
+    starts and carried in the final line, so that a multi-GPU run that dies later still says how far the links got:
+      * `ncclCommCount` / the device every RCCL rank bound (`rccl_ranks_seen`, `rccl_devices`);
+      * the reference's known answers (tests/kernel/test_comm.py:96-149) through RCCL and through the peer-to-peer kernels,
+        each at the three message sizes of the path -- 256 KB (one-shot range), 2.6 MB ([256, hidden] decode all-reduce),
+        84 MB ([8192, hidden] prefill chunk; RCCL only unless the mapped buffers were sized for it);
+      * all-reduce time and bus bandwidth per path and size: busbw = 2 (n - 1) / n x bytes / t, to be read
+        against one xGMI link (153 GB/s, ring) and all seven (peer-to-peer kernels)."""
     import torch.distributed as dist
 
-    out = {"p2p": "ok (one-shot / two-shot / all-gather known answers)" if comm.p2p is not None else "absent: RCCL carries every message"}
+    sizes = {"256KB": 256 * 1024, "2.6MB": 256 * 5120 * 2, "84MB": 8192 * 5120 * 2}
+    paths = {}
+    if comm.rccl is not None:
+        paths["rccl"] = (comm.rccl.all_reduce, comm.rccl.all_gather, lambda nbytes: True)
+    if comm.p2p is not None:
+        paths["p2p"] = (comm.p2p.all_reduce, comm.p2p.all_gather, lambda nbytes: nbytes <= comm.p2p.max_bytes)
+    out = {"p2p": "ok (one-shot / two-shot / all-gather self-test at init)" if comm.p2p is not None else "absent: RCCL carries every message",
+           "known_answers": {}, "all_reduce": {}}
+    for pname, (ar, ag, fits) in paths.items():
+        for sname, nbytes in sizes.items():
+            key = f"{pname} {sname}"
+            if not fits(nbytes):
+                out["known_answers"][key] = "skipped: larger than the mapped peer buffers (this size goes through RCCL)"
+                continue
+            try:
+                bad = _known_answers(ar, ag, rank, world, device, nbytes // 2)
+                x = torch.ones(nbytes // 2, dtype=torch.bfloat16, device=device)
+                for _ in range(3):
+                    ar(x)
+                    x.fill_(1.0)
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 10
+                e0.record()
+                for _ in range(reps):
+                    ar(x)
+                e1.record()
+                e1.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+            except Exception as e:  # noqa: BLE001 -- the report must survive a broken path
+                bad, us = [f"{type(e).__name__}: {e}"], None
+            everyone = [None] * world
+            dist.all_gather_object(everyone, (bad, us))
+            fails = [f"rank {r}: {'; '.join(b)}" for r, (b, _) in enumerate(everyone) if b]
+            out["known_answers"][key] = "pass" if not fails else "FAIL " + " | ".join(fails)
+            times = [u for _, u in everyone if u is not None]
+            if times:
+                t = max(times)
+                out["all_reduce"][key] = {"us": t, "busbw_GBps": 2.0 * (world - 1) / world * nbytes / t / 1e3}
     if comm.rccl is not None:
         info = comm.rccl.info()
-        x = torch.full((1 << 20,), float(rank + 1), dtype=torch.bfloat16, device=device)
-        comm.rccl.all_reduce(x)
-        torch.cuda.synchronize(device)
-        ok = bool((x == float(world * (world + 1) // 2)).all())
         devs = [None] * world
-        dist.all_gather_object(devs, (info["nranks"], info["device"], ok))
-        out.update(rccl_ranks_seen=min(d[0] for d in devs), rccl_devices=[d[1] for d in devs],
-                   rccl_known_answer_ok=all(d[2] for d in devs))
+        dist.all_gather_object(devs, (info["nranks"], info["device"]))
+        out.update(rccl_ranks_seen=min(d[0] for d in devs), rccl_devices=[d[1] for d in devs])
     else:
-        out.update(rccl_ranks_seen=0, rccl_devices=[], rccl_known_answer_ok=None)
+        out.update(rccl_ranks_seen=0, rccl_devices=[])
+    out["rccl_known_answer_ok"] = (all(v == "pass" for k, v in out["known_answers"].items() if k.startswith("rccl"))
+                                   if comm.rccl is not None else None)
+    out["p2p_known_answer_ok"] = (all(v == "pass" or v.startswith("skipped") for k, v in out["known_answers"].items() if k.startswith("p2p"))
+                                  if comm.p2p is not None else None)
+    LAST_PREFLIGHT.clear()
+    LAST_PREFLIGHT.update(out)
+    if rank == 0:
+        print("[bench preflight] " + json.dumps(out), file=sys.stderr, flush=True)
     return out
 
 
@@ -615,7 +699,17 @@ def main() -> None:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    result = run_workload(args, args.model, rank, local_rank, world, device, share_gpu, primary=True)
+    try:
+        result = run_workload(args, args.model, rank, local_rank, world, device, share_gpu, primary=True)
+    except BaseException as e:  # noqa: BLE001
+        if world > 1 and rank == 0:
+            # a multi-GPU run that dies after its preflight still leaves ONE line saying how far the links got
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+                              "data": "synthetic", "config": {"workload": f"{args.model} bf16 decode step (FAILED before a measurement)",
+                                                               "parallelism": f"tp{world}"},
+                              "error": f"{type(e).__name__}: {e}", "collectives": dict(LAST_PREFLIGHT) or None}), flush=True)
+        raise
     result["launch"] = ("self-launched: bench.py started its ranks through torch.distributed.run"
                         if os.environ.get("MSGL_BENCH_SELF_LAUNCHED") == "1" else
                         "external launcher (torchrun)" if world > 1 else "single process")

@@ -1135,7 +1135,9 @@ static int decode_impl() {
   return g_decode_impl;
 }
 // matrix-core kernel variants: code = 10 * (waves per SIMD) + ring stages.  Two stages (deeper rings measured the same or
-// slower in rounds 2-3: profiles/r02d_decode_ab.txt; round 6 removed their instantiations) at the residency the plan is made
+// slower in rounds 2-3: profiles/r02d_decode_ab.txt, and again in round 6 on the whole-line request shape -- 3 / 4 stages at
+// two waves per SIMD and 3 / 4 / 6 stages at one: 146.5 ... 151.8 us against 147.6 at Qwen3-14B TP1, profiles/
+// r06h_decode_ab_ring_depth_and_residency.txt; their instantiations are not kept) at the residency the plan is made
 // for -- three waves per SIMD where the streaming kernel also has three (G <= 2), two otherwise.  92 = variant 22 without the
 // products (diagnosis).
 static int mfma_variant(int G) {

@@ -50,9 +50,25 @@ def _worker(rank, world, port, q):
         g = all_gather(torch.full((8,), float(rank), dtype=torch.bfloat16))
         assert torch.equal(g, torch.arange(world, dtype=torch.bfloat16).repeat_interleave(8))
 
-        # ---- the PRODUCT's sharding (DenseDecoder.load_hf_state on this rank) == the oracle's shard of the same weights
+        # ---- bench.py's multi-GPU preflight runs the SAME known answers (in place, its collective seam) before a --gpus N run:
+        #      exercised here over gloo so that the code a first 8-GPU run depends on has run at world 2 somewhere
         import sys
         from pathlib import Path
+
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+        import bench
+
+        def ar_inplace(t):
+            t.copy_(all_reduce(t))
+
+        def ag_into(dst, src):
+            dst.copy_(all_gather(src))
+
+        assert bench._known_answers(ar_inplace, ag_into, rank, world, torch.device("cpu"), 4096) == []
+        wrong = bench._known_answers(lambda t: None, ag_into, rank, world, torch.device("cpu"), 4096)  # a collective that does nothing
+        assert len(wrong) >= 2 and "ones x4" in wrong[0]
+
+        # ---- the PRODUCT's sharding (DenseDecoder.load_hf_state on this rank) == the oracle's shard of the same weights
 
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         import refdrive

@@ -10,6 +10,7 @@
 #   trace_step        rocprofv3 kernel trace of the timed steps -> <tag>_bench_timed_steps_kernel_breakdown.txt
 #   rank_shard        bench.py --rank-shard on the five TP configurations
 #   trace_replay:<model>[:<requests>]  tools/trace_replay.py at the reference's six scales, --cache naive
+#   tp2_share[:<model>]  bench.py --gpus 2 with both ranks on one GPU (code-path check, incl. the collectives preflight)
 #   smoke             __graft_entry__.smoke()
 #   py:<script args>  python tools/<script args>
 TAG=$1; shift
@@ -59,6 +60,13 @@ PY
     trace_replay)
       IFS=: read -r MODEL NREQ <<< "$ARG"
       ( time timeout 1700 python tools/trace_replay.py --model ${MODEL:-qwen3-14b} --requests ${NREQ:-300} --out gpurun_out/${TAG}_trace_replay_${MODEL:-qwen3-14b}_tp1.json ) 2>&1 | tail -12 | cut -c1-400 ;;
+    tp2_share)  # bench.py --gpus 2 self-launched with both ranks on ONE GPU (code-path check of the N > 1 path incl. the preflight)
+      ( time MSGL_BENCH_SHARE_GPU=1 MSGL_GEMM_TUNE=off timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --model ${ARG:-qwen3-0.6b} ) > gpurun_out/${TAG}_bench_tp2_share.json 2> gpurun_out/${TAG}_bench_tp2_share.err
+      grep "bench preflight" gpurun_out/${TAG}_bench_tp2_share.err | cut -c1-1500; tail -3 gpurun_out/${TAG}_bench_tp2_share.err | cut -c1-300
+      python -c "
+import json
+d=json.loads(open('gpurun_out/${TAG}_bench_tp2_share.json').read().strip().splitlines()[-1])
+print('N=2 on one GPU:', d.get('launch'), '| ms/step', d.get('ms_per_step'), '|', json.dumps(d.get('collectives'))[:1200])" 2>&1 | tail -3 ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     py) ( time timeout 900 python tools/$ARG ) 2>&1 | tail -40 | cut -c1-300 ;;
     *) echo "unknown job $JOB" ;;
