@@ -11,6 +11,7 @@
 #   rank_shard        bench.py --rank-shard on the five TP configurations
 #   trace_replay:<model>[:<requests>]  tools/trace_replay.py at the reference's six scales, --cache naive
 #   tp2_share[:<model>]  bench.py --gpus 2 with both ranks on one GPU (code-path check, incl. the collectives preflight)
+#   pmc_attn          rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes + kernel trace of the decode attention launch -> <tag>_pmc_attn_decode.json
 #   smoke             __graft_entry__.smoke()
 #   py:<script args>  python tools/<script args>
 TAG=$1; shift
@@ -67,6 +68,28 @@ PY
 import json
 d=json.loads(open('gpurun_out/${TAG}_bench_tp2_share.json').read().strip().splitlines()[-1])
 print('N=2 on one GPU:', d.get('launch'), '| ms/step', d.get('ms_per_step'), '|', json.dumps(d.get('collectives'))[:1200])" 2>&1 | tail -3 ;;
+    pmc_attn)  # HBM traffic of the decode attention launch: separate --pmc passes (+ the probe's nt whole-line kernel as a second calibration)
+      cd /tmp && export TMPDIR=/tmp
+      for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --pmc $C -d $R/gpurun_out/${TAG}_pmc_$C -- python $R/tools/profile_attn.py --advance 26 > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+        DB=$(find $R/gpurun_out/${TAG}_pmc_$C -name "*results.db" | head -1)
+        timeout 120 python $R/tools/rocpd_summary.py $DB --top 12 > $R/gpurun_out/${TAG}_pmc_$C.txt 2>&1
+        grep -A6 "kernel,counter" $R/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-160
+        find $R/gpurun_out/${TAG}_pmc_$C -name "*.db" -delete
+      done
+      timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pmc_probe -- $R/tools/build/kv_stream_probe 1 > $R/gpurun_out/${TAG}_pmc_probe.log 2>&1
+      DB=$(find $R/gpurun_out/${TAG}_pmc_probe -name "*results.db" | head -1)
+      timeout 120 python $R/tools/rocpd_summary.py $DB --top 24 > $R/gpurun_out/${TAG}_pmc_probe_FETCH_SIZE.txt 2>&1
+      grep -A12 "kernel,counter" $R/gpurun_out/${TAG}_pmc_probe_FETCH_SIZE.txt | cut -c1-160
+      find $R/gpurun_out/${TAG}_pmc_probe -name "*.db" -delete
+      timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_attn_kt -- python $R/tools/profile_attn.py --advance 26 > $R/gpurun_out/${TAG}_attn_kt.log 2>&1
+      DB=$(find $R/gpurun_out/${TAG}_attn_kt -name "*results.db" | head -1)
+      timeout 120 python $R/tools/rocpd_summary.py $DB --top 8 > $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt 2>&1; cut -c1-160 $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt | head -8
+      find $R/gpurun_out/${TAG}_attn_kt -name "*.db" -delete
+      ALGO=$(grep algorithmic_bytes_per_launch $R/gpurun_out/${TAG}_attn_kt.log | awk '{print $2}')
+      python $R/tools/pmc_json.py $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt \
+        $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt $ALGO $R/gpurun_out/${TAG}_pmc_attn_decode.json "tools/gpu_job.sh $TAG pmc_attn" | cut -c1-600
+      cd $R ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     py) ( time timeout 900 python tools/$ARG ) 2>&1 | tail -40 | cut -c1-300 ;;
     *) echo "unknown job $JOB" ;;
