@@ -369,7 +369,7 @@ int msgl_g3_gemm_nt(void* out, const void* x, const void* w, int M, int N, int K
                     int64_t ldo, int dtype, int grid, int full, int tail_split, int flags, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
-/* Row-owner generation of the decode projection (csrc/gemm_ro.hip), 8 < M <= 256: the same `F.linear` of
+/* Row-owner generation of the decode projection (csrc/gemm_ro.hip), planned for 3 <= M <= 256 (the entry point takes 1 <= M <= 256): the same `F.linear` of
  * P/layers/linear.py:32,103,124 (and the LM head, P/layers/embedding.py:98).  The N / 16 sixteen-row units of `w` are cut
  * into `tiles` balanced contiguous ranges (widths differ by at most one unit; at most msgl_ro_gemm_max_units(M) units each)
  * and every range into `slices` k-slices; item (tile, slice) runs on workgroup (tile * slices + slice) % grid, grid = min(CU

@@ -547,7 +547,9 @@ int msgl_gemm_set_plan(int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ld
   pl.algo_index = algo_index;
   pl.split_k = split_k;
   pl.tuned = true;
-  g_plans[Key{dev, M, N, K, ldx, ldw, ldo, dtype}] = pl;
+  const Key key{dev, M, N, K, ldx, ldw, ldo, dtype};
+  g_plans[key] = pl;
+  g_finalists.erase(key);  // an imported plan has no search behind it: a later select_finalist(0) must not silently replace it
   return MSGL_OK;
 }
 

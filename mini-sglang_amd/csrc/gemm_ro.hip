@@ -1,4 +1,4 @@
-// Decode projection GEMM, "row-owner" generation (round 5), 8 < M <= 256:
+// Decode projection GEMM, "row-owner" generation (round 5), planned for 3 <= M <= 256 (takes M >= 1):
 //     out[M, N] = x[M, K] . w[N, K]^T        (torch F.linear layout, bf16 / fp16, fp32 accumulate)
 //
 // What gemm_g3.hip left on the table ("What bounds the full-batch projections"):

@@ -555,7 +555,9 @@ def rowstream_planned(M: int, w: torch.Tensor, mode: int = 0):
     N, K = w.shape
     key = (w.device.index or 0, M, N, K, K, w.stride(0), _dt(w))
     plan = _SKINNY_PLAN.get(key)
-    if not plan or plan[0] > 0 or _WSTREAM_PLAN.get(key) or not rowstream_supported(M, N, K, mode, -plan[0]):
+    # (a shape whose plan is the row-owner kernel is NOT this kernel's, whatever the skinny table still holds: linear() looks at
+    # _RO_PLAN first, and the fold must take the same kernel as the plain launch -- ADVICE r5)
+    if not plan or plan[0] > 0 or _WSTREAM_PLAN.get(key) or _RO_PLAN.get(key) or not rowstream_supported(M, N, K, mode, -plan[0]):
         return None
     return plan[1], -plan[0]
 
@@ -957,7 +959,7 @@ def g3_linear(x: torch.Tensor, w: torch.Tensor, grid: int, full: int, tail_split
     return out
 
 
-# ---- row-owner generation (csrc/gemm_ro.hip), 8 < M <= 256: balanced 16-row-unit tiles x k-slices, plan = (tiles, slices)
+# ---- row-owner generation (csrc/gemm_ro.hip), RO_MIN_M = 3 <= M <= 256: balanced 16-row-unit tiles x k-slices, plan = (tiles, slices)
 _RO_PLAN: dict = {}       # plan key -> (tiles, slices)
 _RO_SILU_PLAN: dict = {}  # plan key (w = interleaved gate_up) -> (tiles, 1): projection + SiLU.mul in one launch
 RO_SILU, RO_SLABS_ONLY = 1, 2
@@ -1243,6 +1245,13 @@ def apply_candidate(key, spec) -> None:
     """Make `spec` the plan of the shape `key` (see _CANDIDATES)."""
     kind, arg = spec
     dev, M, N, K, ldx, ldw, dt = key
+    if kind in ("lib", "hand", "ro", "fused", "ro_silu"):
+        # linear() / linear_silu() consult the skinny / weight-streaming tables BEFORE these: a candidate timed under its own
+        # label must be the kernel that runs (ADVICE r5; the re-ranking runs at the largest graph batch, where they are empty)
+        _SKINNY_SILU_PLAN.pop(key, None)
+        _SKINNY_PLAN.pop(key, None)
+        if kind != "hand":
+            _WSTREAM_PLAN.pop(key, None)
     if kind == "lib":
         _M256_PLAN.pop(key, None)
         _WSTREAM_PLAN.pop(key, None)
@@ -1271,13 +1280,14 @@ def apply_candidate(key, spec) -> None:
 
 def snapshot_plan(key):
     """Opaque state of the shape's hand-written plans (the library's pick is restored by index 0 of its finalists)."""
-    return (_M256_PLAN.get(key), _WSTREAM_PLAN.get(key), _FUSED_SILU_PLAN.get(key), _RO_PLAN.get(key), _RO_SILU_PLAN.get(key))
+    return (_M256_PLAN.get(key), _WSTREAM_PLAN.get(key), _FUSED_SILU_PLAN.get(key), _RO_PLAN.get(key), _RO_SILU_PLAN.get(key),
+            _SKINNY_PLAN.get(key), _SKINNY_SILU_PLAN.get(key))
 
 
 def restore_search_pick(key, snap) -> None:
     """Back to what the back-to-back search left for the shape: its hand-written plans (`snap`) and, on the library
     side, the fastest finalist (= the search's own pick: the finalists are sorted by its times)."""
-    for d, v in zip((_M256_PLAN, _WSTREAM_PLAN, _FUSED_SILU_PLAN, _RO_PLAN, _RO_SILU_PLAN), snap):
+    for d, v in zip((_M256_PLAN, _WSTREAM_PLAN, _FUSED_SILU_PLAN, _RO_PLAN, _RO_SILU_PLAN, _SKINNY_PLAN, _SKINNY_SILU_PLAN), snap):
         if v is None:
             d.pop(key, None)
         else:
@@ -1320,9 +1330,10 @@ def import_gemm_plans(plans: dict, device_index: int = 0, reset: bool = True) ->
             key = ast.literal_eval(k)
             _PLAN_TABLES[name][(device_index,) + tuple(key[1:])] = tuple(v)
     ws = gemm_workspace(torch.device("cuda", device_index))
-    for M, N, K, ldx, ldw, ldo, dt, idx, sk in plans["library"]:
-        _lib.check_gemm(_lib.gemm_lib().msgl_gemm_set_plan(M, N, K, ldx, ldw, ldo, dt, idx, sk, ws.data_ptr(), ws.numel()),
-                        "gemm_set_plan")
+    with torch.cuda.device(device_index):  # msgl_gemm_set_plan files the plan under the CURRENT HIP device's handle
+        for M, N, K, ldx, ldw, ldo, dt, idx, sk in plans["library"]:
+            _lib.check_gemm(_lib.gemm_lib().msgl_gemm_set_plan(M, N, K, ldx, ldw, ldo, dt, idx, sk, ws.data_ptr(), ws.numel()),
+                            "gemm_set_plan")
 
 
 def reset_gemm_plans() -> None:
