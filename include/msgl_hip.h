@@ -198,12 +198,15 @@ int msgl_attn_decode(void* out, const void* q, const void* k_cache, const void* 
                      int64_t q_stride_tok, int64_t kv_stride_tok, int64_t kv_stride_head,
                      int64_t out_stride_tok, float sm_scale, int slot_run, int dtype, void* stream);
 /* Which partial-attention kernel msgl_attn_decode_plan / msgl_attn_decode use from now on (process-wide; plan and
- * launch must be made under the same choice): 0 = default (matrix-core kernel for slot_run >= 16, streaming kernel
- * otherwise), 1 = streaming kernel only; for timing and diagnosis also 10 w + s = matrix-core kernel held to w waves
- * per SIMD with an s-stage request ring (22, 23, 24, 32), 72 = variant 22 with the in-kernel combine instead of
- * the merge kernel, 71 = the default variant by number (72's A/B partner), 92 = variant 22 with the products left out (what the request pattern alone costs), 93 =
- * variant 22 leaving clock stamps (msgl_attn_decode_trace).  Also settable by
- * MSGL_DECODE_IMPL before the first call.  Both kernels meet the same tolerance against the oracle. */
+ * launch must be made under the same choice): 0 = default = the matrix-core kernel for every slot_run (round 6: token-granular
+ * tables, slot_run < 16, are gathered by per-lane addresses on the same kernel; whole-line nt requests with K transposed through
+ * LDS where a token row is >= 1 KB, round 5's 16-row x 64-B direct-to-operand requests below), 1 = the round-1 streaming kernel
+ * only; for timing and diagnosis also 22 / 32 = matrix-core kernel held to 2 / 3 waves per SIMD (two-stage request ring), 60 / 61 =
+ * the default variant with the round-5 / the whole-line request shape forced (same bits either way), 72 = variant 22 with the
+ * in-kernel combine instead of the merge kernel, 71 = the default variant by number (72's A/B partner), 92 = variant 22 with the
+ * products left out (what the request pattern alone costs), 93 = variant 22 leaving clock stamps (msgl_attn_decode_trace), 94 =
+ * variant 22 without the per-piece record prefetch.  Also settable by MSGL_DECODE_IMPL before the first call.  Both kernels meet
+ * the same tolerance against the oracle. */
 int msgl_attn_decode_select(int impl);
 /* Diagnosis: under msgl_attn_decode_select(93) every wave leaves 16 uint64 shader-clock stamps at stamps[16 * wave]:
  * [0] entry, [1] slot known, then per piece i: [2 + 4 i] metadata known, [3 + 4 i] first tile arrived, [4 + 4 i] last
@@ -214,7 +217,8 @@ int msgl_attn_decode_trace(void* stamps);
 /* slot_run: the caller's guarantee that every ALIGNED run of slot_run positions of a request maps to
  * consecutive token slots (= the engine's page_size under the reference's page-aligned allocation,
  * P/scheduler/cache.py:42-53,127-146; the property fa.py:92-97 relies on).  1 = no guarantee.
- * With slot_run >= 16 the kernel reads one table entry per 16-token tile through the scalar cache. */
+ * With slot_run >= 16 the kernel reads one table entry per 16-token tile through the scalar cache; below, each 16-lane group
+ * of a wave reads the four entries of its four tokens as one 16-byte load per tile. */
 
 /* ------------------------------------------------------------------------
  * Paged varlen causal prefill attention (MFMA).  Replaces the prefill phase
