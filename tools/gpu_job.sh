@@ -12,6 +12,7 @@
 #   trace_replay:<model>[:<requests>]  tools/trace_replay.py at the reference's six scales, --cache naive
 #   tp2_share[:<model>]  bench.py --gpus 2 with both ranks on one GPU (code-path check, incl. the collectives preflight)
 #   pmc_attn          rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes + kernel trace of the decode attention launch -> <tag>_pmc_attn_decode.json
+#   pmc_lm_head       FETCH_SIZE / WRITE_SIZE / L2-request counters + kernel trace of the LM head (library solution and row-owner kernel)
 #   smoke             __graft_entry__.smoke()
 #   py:<script args>  python tools/<script args>
 TAG=$1; shift
@@ -89,6 +90,21 @@ print('N=2 on one GPU:', d.get('launch'), '| ms/step', d.get('ms_per_step'), '|'
       ALGO=$(grep algorithmic_bytes_per_launch $R/gpurun_out/${TAG}_attn_kt.log | awk '{print $2}')
       python $R/tools/pmc_json.py $R/gpurun_out/${TAG}_pmc_FETCH_SIZE.txt $R/gpurun_out/${TAG}_pmc_WRITE_SIZE.txt \
         $R/gpurun_out/${TAG}_attn_decode_kernel_trace.txt $ALGO $R/gpurun_out/${TAG}_pmc_attn_decode.json "tools/gpu_job.sh $TAG pmc_attn" | cut -c1-600
+      cd $R ;;
+    pmc_lm_head)
+      cd /tmp && export TMPDIR=/tmp
+      for C in FETCH_SIZE WRITE_SIZE "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum"; do
+        NAME=$(echo $C | tr ' ' '_')
+        timeout 300 rocprofv3 --pmc $C -d $R/gpurun_out/${TAG}_pmclm_$NAME -- python $R/tools/pmc_lm_head.py > $R/gpurun_out/${TAG}_pmclm_$NAME.log 2>&1
+        DB=$(find $R/gpurun_out/${TAG}_pmclm_$NAME -name "*results.db" | head -1)
+        timeout 120 python $R/tools/rocpd_summary.py $DB --top 8 > $R/gpurun_out/${TAG}_pmc_lm_head_$NAME.txt 2>&1
+        grep -A8 "kernel,counter" $R/gpurun_out/${TAG}_pmc_lm_head_$NAME.txt | cut -c1-200
+        find $R/gpurun_out/${TAG}_pmclm_$NAME -name "*.db" -delete
+      done
+      timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_pmclm_kt -- python $R/tools/pmc_lm_head.py > $R/gpurun_out/${TAG}_pmclm_kt.log 2>&1
+      DB=$(find $R/gpurun_out/${TAG}_pmclm_kt -name "*results.db" | head -1)
+      timeout 120 python $R/tools/rocpd_summary.py $DB --top 6 > $R/gpurun_out/${TAG}_pmc_lm_head_kernel_trace.txt 2>&1; cut -c1-200 $R/gpurun_out/${TAG}_pmc_lm_head_kernel_trace.txt | head -8; grep algorithmic $R/gpurun_out/${TAG}_pmclm_kt.log
+      find $R/gpurun_out/${TAG}_pmclm_kt -name "*.db" -delete
       cd $R ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     py) ( time timeout 900 python tools/$ARG ) 2>&1 | tail -40 | cut -c1-300 ;;
