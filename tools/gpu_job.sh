@@ -26,7 +26,8 @@ for JOB in "$@"; do
     kv_probe)
       mkdir -p tools/build
       [ -x tools/build/kv_stream_probe ] || hipcc -O3 --offload-arch=gfx950 tools/kv_stream_probe.hip -o tools/build/kv_stream_probe
-      timeout 300 tools/build/kv_stream_probe ${ARG:-3} > gpurun_out/${TAG}_kv_stream_probe.txt 2>&1; cat gpurun_out/${TAG}_kv_stream_probe.txt | cut -c1-200 ;;
+      timeout 300 tools/build/kv_stream_probe ${ARG:-3} > gpurun_out/${TAG}_kv_stream_probe.txt 2>&1  # kv_probe:<rounds>[ <skew %>]
+      cat gpurun_out/${TAG}_kv_stream_probe.txt | cut -c1-200 ;;
     decode_ab)  # decode_ab:<impls>[:<page>[:<alloc>]]
       IFS=: read -r IMPLS PAGE ALLOC <<< "$ARG"
       SUF=""; [ -n "$PAGE" ] && SUF="_page${PAGE}_${ALLOC:-shuffled}"

@@ -49,11 +49,15 @@ enum { REG_M = 0, REG_K = 1, REG_T = 2, DMA_K = 3, DMA_T = 4 };
 
 template <int PAT, int AUX>
 __global__ __launch_bounds__(512, 2) void rd(const char* __restrict__ kbase, const char* __restrict__ vbase,
-                                             const int* __restrict__ page_of, int tiles, uint32_t* __restrict__ out) {
+                                             const int* __restrict__ page_of, int tiles_in, uint32_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int slot = blockIdx.x;
+  // skew experiment (argv[2], percent in bits 16.. of tiles_in): the first wave of every SIMD (w < 4) streams (100 + skew) %
+  // of the tiles, the second (100 - skew) % -- does handing the arbitration's favourite more work shorten the launch?
+  const int skew = tiles_in >> 16, base_tiles = tiles_in & 0xffff;
+  const int tiles = (PAT <= REG_T || PAT == DMA_K) ? base_tiles * (w < 4 ? 100 + skew : 100 - skew) / 100 : base_tiles;
   const CInt* pages = (const CInt*)page_of;
   // byte offset of the lane's piece inside a tile, per load j
   int off[4];
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void rd(const char* __restrict__ kbase, con
     else off[j] = (4 * w + j) * 1024 + lane * 16;
   }
   auto tile_base = [&](int ti) -> int64_t {
-    const int g = slot * tiles + ti;
+    const int g = slot * base_tiles + ti;
     const int page = pages[g / kPageTiles];
     return ((int64_t)page * kPageTiles + (g % kPageTiles)) * kTileBytes;
   };
@@ -182,9 +186,10 @@ struct Case {
 int main(int argc, char** argv) {
   const int G = 256;
   const int rounds = argc > 1 ? atoi(argv[1]) : 3;
+  const int skew = argc > 2 ? atoi(argv[2]) : 0;
   const int tile_counts[2] = {58, 128};
   const int max_tiles = 128;
-  const int n_pages = (G * max_tiles + kPageTiles - 1) / kPageTiles + 1;
+  const int n_pages = (G * max_tiles + max_tiles + kPageTiles - 1) / kPageTiles + 2;  // (+ one slot: a skewed wave runs past its own)
   const size_t slab = (size_t)n_pages * kPageTiles * kTileBytes;
   char *k, *v;
   int* pages;
@@ -222,10 +227,10 @@ int main(int argc, char** argv) {
     for (int r = 0; r < rounds; ++r) {
       for (int ci = 0; ci < n_cases; ++ci) {
         const Case& c = cases[ci];
-        for (int i = 0; i < 5; ++i) c.kernel<<<G, 512, c.lds>>>(k, v, pages, tiles, out);
+        for (int i = 0; i < 5; ++i) c.kernel<<<G, 512, c.lds>>>(k, v, pages, tiles | (skew << 16), out);
         const int iters = 20;
         CHECK(hipEventRecord(e0));
-        for (int i = 0; i < iters; ++i) c.kernel<<<G, 512, c.lds>>>(k, v, pages, tiles, out);
+        for (int i = 0; i < iters; ++i) c.kernel<<<G, 512, c.lds>>>(k, v, pages, tiles | (skew << 16), out);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -233,7 +238,7 @@ int main(int argc, char** argv) {
         us[ci].push_back(ms * 1e3 / iters);
       }
     }
-    printf("tiles per workgroup %d (%.0f MB per launch)\n", tiles, bytes / 1e6);
+    printf("tiles per workgroup %d (%.0f MB per launch), skew %d %%\n", tiles, bytes / 1e6, skew);
     for (int ci = 0; ci < n_cases; ++ci) {
       std::sort(us[ci].begin(), us[ci].end());
       const double med = us[ci][us[ci].size() / 2];
