@@ -79,6 +79,7 @@ print('N=2 on one GPU:', d.get('launch'), '| ms/step', d.get('ms_per_step'), '|'
         grep -A6 "kernel,counter" $R/gpurun_out/${TAG}_pmc_$C.txt | cut -c1-160
         find $R/gpurun_out/${TAG}_pmc_$C -name "*.db" -delete
       done
+      mkdir -p $R/tools/build; [ -x $R/tools/build/kv_stream_probe ] || hipcc -O3 --offload-arch=gfx950 $R/tools/kv_stream_probe.hip -o $R/tools/build/kv_stream_probe
       timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pmc_probe -- $R/tools/build/kv_stream_probe 1 > $R/gpurun_out/${TAG}_pmc_probe.log 2>&1
       DB=$(find $R/gpurun_out/${TAG}_pmc_probe -name "*results.db" | head -1)
       timeout 120 python $R/tools/rocpd_summary.py $DB --top 24 > $R/gpurun_out/${TAG}_pmc_probe_FETCH_SIZE.txt 2>&1
